@@ -1,0 +1,100 @@
+"""ctypes binding of libhmg_hip.so (C ABI: include/hmg.h).  No fallback: if the HIP library has not
+been built, importing the compute API fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhmg_hip.so")
+
+c_i64 = ctypes.c_int64
+c_f64 = ctypes.c_double
+c_int = ctypes.c_int
+vp = ctypes.c_void_p
+p_i64 = ctypes.POINTER(ctypes.c_int64)
+p_i32 = ctypes.POINTER(ctypes.c_int32)
+p_f64 = ctypes.POINTER(ctypes.c_double)
+pp = ctypes.POINTER(ctypes.c_void_p)
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+
+# name -> (restype, argtypes); every symbol declared in include/hmg.h
+SIGNATURES = {
+    "hmg_last_error": (ctypes.c_char_p, []),
+    "hmg_version": (c_int, []),
+    "hmg_ctx_create": (c_int, [c_int, vp, pp]),
+    "hmg_ctx_destroy": (c_int, [vp]),
+    "hmg_ctx_sync": (c_int, [vp]),
+    "hmg_ctx_set_option": (c_int, [vp, ctypes.c_char_p, c_i64]),
+    "hmg_ctx_set_option_f64": (c_int, [vp, ctypes.c_char_p, c_f64]),
+    "hmg_ctx_scalar_bank": (vp, [vp]),
+    "hmg_grid_create": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, pp]),
+    "hmg_grid_destroy": (c_int, [vp]),
+    "hmg_grid_set_operator": (c_int, [vp, p_f64, c_f64]),
+    "hmg_grid_set_lambda": (c_int, [vp, c_f64]),
+    "hmg_grid_shrink": (c_int, [vp, c_i64, c_i64]),
+    "hmg_grid_ncells": (c_i64, [vp]),
+    "hmg_grid_nnodes": (c_i64, [vp]),
+    "hmg_grid_nlevels": (c_int, [vp]),
+    "hmg_grid_nf": (c_i64, [vp, c_int]),
+    "hmg_grid_ld": (c_i64, [vp, c_int]),
+    "hmg_grid_table_i32": (c_int, [vp, c_int, ctypes.c_char_p, p_i32, c_i64, p_i64]),
+    "hmg_grid_table_f64": (c_int, [vp, c_int, ctypes.c_char_p, p_f64, c_i64, p_i64]),
+    "hmg_vec_create": (c_int, [vp, c_int, pp]),
+    "hmg_vec_wrap": (c_int, [vp, c_int, vp, pp]),
+    "hmg_vec_destroy": (c_int, [vp]),
+    "hmg_vec_device_ptr": (vp, [vp]),
+    "hmg_vec_upload": (c_int, [vp, p_f64]),
+    "hmg_vec_download": (c_int, [vp, p_f64]),
+    "hmg_vec_fill": (c_int, [vp, c_f64]),
+    "hmg_vec_fill_random": (c_int, [vp, ctypes.c_uint64, c_i64]),
+    "hmg_vec_copy": (c_int, [vp, vp]),
+    "hmg_vec_axpy": (c_int, [c_f64, vp, vp]),
+    "hmg_vec_xpby": (c_int, [vp, c_f64, vp]),
+    "hmg_vec_dot": (c_int, [vp, vp, p_f64]),
+    "hmg_vec_norm_unique": (c_int, [vp, p_f64]),
+    "hmg_apply": (c_int, [vp, c_int, c_f64, vp, vp]),
+    "hmg_residual": (c_int, [vp, c_int, vp, vp, vp]),
+    "hmg_constraint": (c_int, [vp, c_int, vp]),
+    "hmg_interface_sum": (c_int, [vp, c_int, vp]),
+    "hmg_zero_duplicates": (c_int, [vp, c_int, vp]),
+    "hmg_restrict": (c_int, [vp, c_int, vp, vp]),
+    "hmg_prolong_add": (c_int, [vp, c_int, vp, vp]),
+    "hmg_gather_base": (c_int, [vp, vp, p_f64]),
+    "hmg_scatter_base": (c_int, [vp, p_f64, vp]),
+    "hmg_smooth": (c_int, [vp, c_int, c_int, vp, vp, vp, vp, vp]),
+    "hmg_coarse_setup": (c_int, [vp]),
+    "hmg_coarse_solve": (c_int, [vp, vp, vp]),
+    "hmg_coarse_last_iterations": (c_int, [vp]),
+    "hmg_vcycle": (c_int, [vp, c_int, c_int, c_int, pp]),
+    "hmg_grid_set_cut": (c_int, [vp, c_i64, c_i64, c_i64, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32]),
+    "hmg_grid_set_exchange": (c_int, [vp, EXCHANGE_FN, EXCHANGE_FN, vp, vp, c_i64]),
+    "hmg_grid_cut_buffer_doubles": (c_i64, [vp, c_int]),
+}
+
+_lib = None
+
+
+class HmgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libhmg_hip.so and declare every entry point.  Raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or `make -C homogenization.jl_amd/csrc`).  There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HmgError(load().hmg_last_error().decode())

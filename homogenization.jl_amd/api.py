@@ -1,0 +1,336 @@
+"""
+Host-side mirror of the reference's level-3 interface (the part of Homogenization.jl that operates on
+level vectors), driving libhmg_hip.so through its C ABI.  Names, argument order and meaning follow the
+reference (bang-less: `mul!` -> `mul`), so parity tests read like the reference's own tests:
+
+    ImplicitFineGrid(base, levels)            src/implicit_fine_grid.jl:13-18
+    ZeroDirichletConstraint                   src/implicit_fine_grid.jl:80-84 (derived by the library)
+    L2PlusDivAGrad(..., lam, sigmas)          src/build_local_operators.jl:26-32
+    LevelState(ncells, nnodes)                src/multigrid.jl:7-25
+    mul / local_residual                      src/apply_local_operators.jl:7-27, 85-133
+    apply_constraint / broadcast_interfaces / zero_out_all_but_one / copy_to_base / distribute
+                                              src/implicit_fine_grid.jl:94-386
+    restrict_to / interpolate_and_sum_to      src/interpolation.jl:52-74
+    smoothing_steps / vcycle / BaseLevel      src/multigrid.jl:30-119
+
+Level vectors live in HBM (FP64, entity-major storage order); `DeviceMatrix` is the
+`AbstractMatrix` stand-in: `.to_host()` / `.from_host()` speak the reference's Nf x Ne column-major
+hierarchical layout.  There is no CPU implementation behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+Tri64 = "Tri64"   # element-type tags (src/grid.jl:29-37)
+Tet64 = "Tet64"
+
+
+def _dim_of(tag):
+    return {Tri64: 2, Tet64: 3, 2: 2, 3: 3}[tag]
+
+
+@dataclass
+class Mesh:
+    """Base mesh (src/grid.jl:19-22). nodes: (Nn, dim) float64; elements: (Ne, dim+1) int64, 1-based,
+    each row ascending (src/implicit_fine_grid.jl:14)."""
+    nodes: np.ndarray
+    elements: np.ndarray
+
+    @property
+    def dim(self):
+        return self.nodes.shape[1]
+
+
+class Context:
+    """One GPU + one HIP stream. stream: a raw hipStream_t (int) such as
+    torch.cuda.current_stream().cuda_stream, or None for a library-owned stream."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self._lib = L.load()
+        h = ctypes.c_void_p()
+        L.check(self._lib.hmg_ctx_create(device, ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)))
+        self.h = h
+        self.device = device
+
+    def sync(self):
+        L.check(self._lib.hmg_ctx_sync(self.h))
+
+    def set_option(self, name: str, value):
+        if isinstance(value, float):
+            L.check(self._lib.hmg_ctx_set_option_f64(self.h, name.encode(), value))
+        else:
+            L.check(self._lib.hmg_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def close(self):
+        if self.h:
+            self._lib.hmg_ctx_destroy(self.h)
+            self.h = None
+
+
+class ImplicitFineGrid:
+    """ImplicitFineGrid(base, levels) + the ZeroDirichletConstraint of the base mesh boundary.
+    ctx=None builds host tables only (no compute)."""
+
+    def __init__(self, ctx: Context | None, base: Mesh, levels: int):
+        self._lib = L.load()
+        self.ctx = ctx
+        self.base = base
+        self.levels = levels
+        nodes = np.ascontiguousarray(base.nodes, dtype=np.float64)
+        cells = np.ascontiguousarray(base.elements, dtype=np.int64)
+        h = ctypes.c_void_p()
+        L.check(self._lib.hmg_grid_create(ctx.h if ctx else None, base.dim, levels, nodes.shape[0],
+                                          nodes.ctypes.data_as(L.p_f64), cells.shape[0],
+                                          cells.ctypes.data_as(L.p_i64), ctypes.byref(h)))
+        self.h = h
+
+    # -- queries -----------------------------------------------------------------------------
+    def nlevels(self):
+        return self.levels
+
+    def ncells(self):
+        return int(self._lib.hmg_grid_ncells(self.h))
+
+    def nnodes_base(self):
+        return int(self._lib.hmg_grid_nnodes(self.h))
+
+    def nf(self, level):
+        return int(self._lib.hmg_grid_nf(self.h, level))
+
+    def ld(self, level):
+        return int(self._lib.hmg_grid_ld(self.h, level))
+
+    def table_i32(self, which, level=1):
+        n = ctypes.c_int64()
+        L.check(self._lib.hmg_grid_table_i32(self.h, level, which.encode(), None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.int32)
+        L.check(self._lib.hmg_grid_table_i32(self.h, level, which.encode(), out.ctypes.data_as(L.p_i32), n.value,
+                                             ctypes.byref(n)))
+        return out
+
+    def table_f64(self, which, level=1):
+        n = ctypes.c_int64()
+        L.check(self._lib.hmg_grid_table_f64(self.h, level, which.encode(), None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.float64)
+        L.check(self._lib.hmg_grid_table_f64(self.h, level, which.encode(), out.ctypes.data_as(L.p_f64), n.value,
+                                             ctypes.byref(n)))
+        return out
+
+    def interior_nodes(self):
+        """list_interior_nodes(base), 0-based (src/grid.jl:176-202)"""
+        return self.table_i32("interior_nodes")
+
+    # -- operator / domain -------------------------------------------------------------------
+    def set_operator(self, sigmas, lam):
+        s = np.ascontiguousarray(sigmas, dtype=np.float64)
+        assert s.shape == (self.base.elements.shape[0], self.base.dim)
+        L.check(self._lib.hmg_grid_set_operator(self.h, s.ctypes.data_as(L.p_f64), float(lam)))
+
+    def set_lambda(self, lam):
+        L.check(self._lib.hmg_grid_set_lambda(self.h, float(lam)))
+
+    def shrink(self, ncells_prefix, nnodes_prefix):
+        L.check(self._lib.hmg_grid_shrink(self.h, ncells_prefix, nnodes_prefix))
+
+    def coarse_setup(self):
+        L.check(self._lib.hmg_coarse_setup(self.h))
+
+    def close(self):
+        if self.h:
+            self._lib.hmg_grid_destroy(self.h)
+            self.h = None
+
+
+class DeviceMatrix:
+    """A level vector: the reference's `Nf x Ne` matrix, resident in HBM."""
+
+    def __init__(self, implicit: ImplicitFineGrid, level: int, device_ptr=None):
+        self._lib = L.load()
+        self.implicit = implicit
+        self.level = level
+        h = ctypes.c_void_p()
+        if device_ptr is None:
+            L.check(self._lib.hmg_vec_create(implicit.h, level, ctypes.byref(h)))
+        else:
+            L.check(self._lib.hmg_vec_wrap(implicit.h, level, ctypes.c_void_p(device_ptr), ctypes.byref(h)))
+        self.h = h
+
+    @property
+    def shape(self):
+        return (self.implicit.nf(self.level), self.implicit.ncells())
+
+    def from_host(self, a):
+        a = np.asfortranarray(a, dtype=np.float64)
+        assert a.shape == self.shape, (a.shape, self.shape)
+        L.check(self._lib.hmg_vec_upload(self.h, a.ctypes.data_as(L.p_f64)))
+        return self
+
+    def to_host(self):
+        out = np.zeros(self.shape, dtype=np.float64, order="F")
+        L.check(self._lib.hmg_vec_download(self.h, out.ctypes.data_as(L.p_f64)))
+        return out
+
+    def fill(self, v):                       # fill!
+        L.check(self._lib.hmg_vec_fill(self.h, float(v)))
+        return self
+
+    def rand(self, seed, cell_offset=0):     # rand! (seeded, layout independent)
+        L.check(self._lib.hmg_vec_fill_random(self.h, int(seed), int(cell_offset)))
+        return self
+
+    def copyto(self, src):                   # copyto!(self, src)
+        L.check(self._lib.hmg_vec_copy(self.h, src.h))
+        return self
+
+    def device_ptr(self):
+        return int(self._lib.hmg_vec_device_ptr(self.h) or 0)
+
+    def close(self):
+        if self.h:
+            self._lib.hmg_vec_destroy(self.h)
+            self.h = None
+
+
+def host_random(shape, seed, cell_offset=0):
+    """numpy twin of hmg_vec_fill_random (hash of (seed, cell, hierarchical node id))."""
+    nf, ne = shape
+    with np.errstate(over="ignore"):
+        idx = ((np.arange(ne, dtype=np.uint64) + np.uint64(cell_offset)) << np.uint64(20))[None, :] | \
+            np.arange(nf, dtype=np.uint64)[:, None]
+        z = np.uint64(seed) + (idx + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return np.asfortranarray((z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0))
+
+
+# BLAS-1 generics used on state vectors (src/multigrid.jl:54,64-68)
+def dot(x: DeviceMatrix, y: DeviceMatrix) -> float:
+    out = ctypes.c_double()
+    L.check(L.load().hmg_vec_dot(x.h, y.h, ctypes.byref(out)))
+    return out.value
+
+
+def axpy(alpha, x: DeviceMatrix, y: DeviceMatrix):
+    L.check(L.load().hmg_vec_axpy(float(alpha), x.h, y.h))
+
+
+def xpby(r: DeviceMatrix, beta, p: DeviceMatrix):
+    """p .= r .+ beta .* p"""
+    L.check(L.load().hmg_vec_xpby(r.h, float(beta), p.h))
+
+
+def norm_unique(r: DeviceMatrix) -> float:
+    """norm(r) after zero_out_all_but_one!(r) -- without destroying r."""
+    out = ctypes.c_double()
+    L.check(L.load().hmg_vec_norm_unique(r.h, ctypes.byref(out)))
+    return out.value
+
+
+class L2PlusDivAGrad:
+    """lam*I - div(sigma grad), sigma constant per coarse cell; carries the Dirichlet constraint
+    (held by the grid).  Mutable lam like the reference's struct."""
+
+    def __init__(self, implicit: ImplicitFineGrid, lam: float, sigmas):
+        self.implicit = implicit
+        self._lam = float(lam)
+        self.sigmas = np.ascontiguousarray(sigmas, dtype=np.float64)
+        implicit.set_operator(self.sigmas, self._lam)
+
+    @property
+    def lam(self):
+        return self._lam
+
+    @lam.setter
+    def lam(self, v):
+        self._lam = float(v)
+        self.implicit.set_lambda(self._lam)
+
+
+class LevelState:
+    """x, b, r, p, Ap of one level (src/multigrid.jl:7-25)."""
+
+    def __init__(self, implicit: ImplicitFineGrid, level: int):
+        self.level = level
+        self.x = DeviceMatrix(implicit, level)
+        self.b = DeviceMatrix(implicit, level)
+        self.r = DeviceMatrix(implicit, level)
+        self.p = DeviceMatrix(implicit, level)
+        self.Ap = DeviceMatrix(implicit, level)
+
+    def handles(self):
+        return [self.x.h, self.b.h, self.r.h, self.p.h, self.Ap.h]
+
+
+def mul(alpha, implicit: ImplicitFineGrid, A: L2PlusDivAGrad, x: DeviceMatrix, y: DeviceMatrix):
+    """y <- alpha*A*x + y   (mul!(alpha, base, A, x, y))"""
+    L.check(L.load().hmg_apply(implicit.h, x.level, float(alpha), x.h, y.h))
+
+
+def local_residual(implicit, A, curr: LevelState, k: int):
+    L.check(L.load().hmg_residual(implicit.h, k, curr.x.h, curr.b.h, curr.r.h))
+
+
+def apply_constraint(x: DeviceMatrix, level: int, implicit: ImplicitFineGrid):
+    L.check(L.load().hmg_constraint(implicit.h, level, x.h))
+
+
+def broadcast_interfaces(x: DeviceMatrix, implicit: ImplicitFineGrid, level: int):
+    L.check(L.load().hmg_interface_sum(implicit.h, level, x.h))
+
+
+def zero_out_all_but_one(x: DeviceMatrix, implicit: ImplicitFineGrid, level: int):
+    L.check(L.load().hmg_zero_duplicates(implicit.h, level, x.h))
+
+
+def restrict_to(y_coarse: DeviceMatrix, implicit: ImplicitFineGrid, x_fine: DeviceMatrix):
+    """restrict_to!(y, P, x) with P = interops[x.level - 1]"""
+    L.check(L.load().hmg_restrict(implicit.h, x_fine.level, x_fine.h, y_coarse.h))
+
+
+def interpolate_and_sum_to(y_fine: DeviceMatrix, implicit: ImplicitFineGrid, x_coarse: DeviceMatrix):
+    L.check(L.load().hmg_prolong_add(implicit.h, y_fine.level, x_coarse.h, y_fine.h))
+
+
+def copy_to_base(implicit: ImplicitFineGrid, v1: DeviceMatrix):
+    u = np.zeros(implicit.nnodes_base())
+    L.check(L.load().hmg_gather_base(implicit.h, v1.h, u.ctypes.data_as(L.p_f64)))
+    return u
+
+
+def distribute(v1: DeviceMatrix, u, implicit: ImplicitFineGrid):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    L.check(L.load().hmg_scatter_base(implicit.h, u.ctypes.data_as(L.p_f64), v1.h))
+
+
+def smoothing_steps(steps, implicit, ops, curr: LevelState, k: int):
+    L.check(L.load().hmg_smooth(implicit.h, k, steps, curr.x.h, curr.b.h, curr.r.h, curr.p.h, curr.Ap.h))
+
+
+class BaseLevel:
+    """Coarse-level solver handle: the library's device-resident Jacobi-PCG on the assembled level-1
+    operator replaces `cholesky(assemble_checkerboard(...)[interior, interior])`."""
+
+    def __init__(self, implicit: ImplicitFineGrid):
+        self.implicit = implicit
+        implicit.coarse_setup()
+
+    def last_iterations(self):
+        return int(L.load().hmg_coarse_last_iterations(self.implicit.h))
+
+
+def vcycle(implicit: ImplicitFineGrid, base: BaseLevel, ops, levels, k: int, steps: int = 2, steps_coarse: int = 2):
+    """vcycle!(implicit, base, ops, levels, k, steps).  steps_coarse = 2 reproduces the reference,
+    which does not forward `steps` to the recursive call (src/multigrid.jl:109)."""
+    arr = (ctypes.c_void_p * (5 * len(levels)))()
+    for i, st in enumerate(levels):
+        for q, h in enumerate(st.handles()):
+            arr[5 * i + q] = h
+    L.check(L.load().hmg_vcycle(implicit.h, k, steps, steps_coarse, arr))

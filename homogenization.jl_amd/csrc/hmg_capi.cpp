@@ -1,0 +1,1033 @@
+// C ABI (include/hmg.h): object lifetimes, table upload, primitive dispatch, smoother and V-cycle
+// orchestration on one HIP stream with device-resident CG scalars.
+#include "../../include/hmg.h"
+#include "hmg_device.hpp"
+#include "hmg_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace hmg;
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " (" #expr ")"); \
+    } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void upload(const std::vector<T> &h, hipStream_t s)
+    {
+        alloc(h.size());
+        if (!h.empty()) {
+            HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    }
+};
+
+struct LevelBufs {
+    DevBuf<uint64_t> meta;
+    DevBuf<double> ctab;
+    DevBuf<int32_t> hier2slot, par_a, par_b, rptr, ridx;
+};
+
+struct CutKind {
+    int64_t nglobal = 0;
+    int64_t nentries = 0;
+    DevBuf<int64_t> gid;
+    DevBuf<int32_t> cell_lid;
+    DevBuf<uint8_t> first;
+};
+
+}  // namespace
+
+struct hmg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf<double> partials, scal;
+    Launch L{};
+    int coarse_maxit = 5000;
+    int coarse_check = 25;
+    double coarse_rtol = 1e-13;
+};
+
+struct hmg_grid {
+    hmg_ctx *ctx = nullptr;
+    int dim = 0, nlevels = 0;
+    std::vector<LevelTables> lt;
+    std::vector<std::unique_ptr<LevelBufs>> lb;
+    std::vector<LevelDev> ld;
+    MeshTables mesh_full, mesh;
+    bool shrunk = false;
+    MeshDev md{};
+    DevBuf<int32_t> d_cells, d_face_pairs, d_edge_ptr, d_edge_ent, d_node_ptr, d_node_ent, d_node_first;
+    DevBuf<uint16_t> d_dmask, d_dupmask;
+    DevBuf<double> d_coef;
+    std::vector<double> sigma, coef;
+    double lambda = 0.0;
+    bool has_op = false;
+    // coarse system
+    CoarseMatrix cm;
+    CoarseDev cd{};
+    bool coarse_ready = false;
+    DevBuf<int32_t> c_rowptr, c_colidx, c_interior;
+    DevBuf<double> c_val, c_diag, c_b, c_x, c_r, c_z, c_p, c_q, c_u;
+    int coarse_last_it = 0;
+    // multi-GPU
+    CutKind cut[3];   // faces, edges, nodes
+    hmg_exchange_fn exchange = nullptr, scalar_sum = nullptr;
+    void *ex_user = nullptr;
+    double *ex_buf = nullptr;
+    int64_t ex_cap = 0;
+
+    const MeshTables &cur() const { return shrunk ? mesh : mesh_full; }
+};
+
+struct hmg_vec {
+    hmg_grid *g = nullptr;
+    int level = 0;
+    double *d = nullptr;
+    bool own = false;
+    int64_t alloc_cells = 0;
+};
+
+namespace {
+
+int fail(const std::exception &e)
+{
+    last_error() = e.what();
+    return 1;
+}
+
+#define HMG_TRY try {
+#define HMG_END                      \
+    }                                \
+    catch (const std::exception &e)  \
+    {                                \
+        return fail(e);              \
+    }                                \
+    return 0;
+
+void need(bool c, const char *msg)
+{
+    if (!c) throw std::runtime_error(msg);
+}
+
+const LevelDev &lev(const hmg_grid *g, int level)
+{
+    need(g != nullptr, "null grid");
+    need(g->ctx != nullptr, "this grid was created without a device context (host tables only): no compute path exists on the CPU");
+    need(level >= 1 && level <= g->nlevels, "level out of range");
+    return g->ld[level - 1];
+}
+
+void check_vec(const hmg_grid *g, int level, const hmg_vec *v, const char *name)
+{
+    if (!v) throw std::runtime_error(std::string("null vector: ") + name);
+    if (v->g != g) throw std::runtime_error(std::string("vector belongs to another grid: ") + name);
+    if (v->level != level) throw std::runtime_error(std::string("vector has the wrong level: ") + name);
+    if (v->alloc_cells < g->md.ncells) throw std::runtime_error(std::string("vector too small: ") + name);
+}
+
+int64_t vec_len(const hmg_vec *v) { return (int64_t)v->g->ld[v->level - 1].ld * v->g->md.ncells; }
+
+void upload_mesh(hmg_grid *g)
+{
+    const MeshTables &M = g->cur();
+    MeshDev &d0 = g->md;
+    d0.dim = M.dim;
+    d0.ncells = M.ncells;
+    d0.nnodes = M.nnodes;
+    if (!g->ctx) return;   // host-only grid (table queries, no device)
+    hipStream_t s = g->ctx->stream;
+    g->d_cells.upload(M.cells, s);
+    g->d_face_pairs.upload(M.face_pairs, s);
+    g->d_edge_ptr.upload(M.edge_ptr, s);
+    g->d_edge_ent.upload(M.edge_ent, s);
+    g->d_node_ptr.upload(M.node_ptr, s);
+    g->d_node_ent.upload(M.node_ent, s);
+    g->d_node_first.upload(M.node_first, s);
+    g->d_dmask.upload(M.dmask, s);
+    g->d_dupmask.upload(M.dupmask, s);
+    MeshDev &d = g->md;
+    d.dim = M.dim;
+    d.ncells = M.ncells;
+    d.nnodes = M.nnodes;
+    d.cells = g->d_cells.p;
+    d.face_pairs = g->d_face_pairs.p;
+    d.nfacepairs = (int64_t)M.face_pairs.size() / 3;
+    d.edge_ptr = g->d_edge_ptr.p;
+    d.edge_ent = g->d_edge_ent.p;
+    d.nsharededges = (int64_t)M.edge_ptr.size() - 1;
+    d.node_ptr = g->d_node_ptr.p;
+    d.node_ent = g->d_node_ent.p;
+    d.nsharednodes = (int64_t)M.node_ptr.size() - 1;
+    d.node_first = g->d_node_first.p;
+    d.dmask = g->d_dmask.p;
+    d.dupmask = g->d_dupmask.p;
+    d.coef = g->d_coef.p;
+}
+
+void upload_operator(hmg_grid *g)
+{
+    const MeshTables &M = g->cur();
+    build_cell_coefficients(M, g->sigma.data(), g->coef);
+    g->coarse_ready = false;
+    if (!g->ctx) return;
+    g->d_coef.upload(g->coef, g->ctx->stream);
+    g->md.coef = g->d_coef.p;
+}
+
+void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);   // defined below
+
+void interface_sum(hmg_grid *g, const LevelDev &lv, double *x)
+{
+    launch_interface_sum(g->ctx->L, lv, g->md, x);
+    if (g->exchange) exchange_cut(g, lv, x);
+}
+
+void scalar_sum(hmg_grid *g, int slot, int count)
+{
+    if (g->scalar_sum) {
+        if (g->scalar_sum(g->ex_user, g->ctx->scal.p + slot, count) != 0)
+            throw std::runtime_error("scalar_sum callback failed");
+    }
+}
+
+void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap)
+{
+    // ref: src/multigrid.jl:46-71
+    const LevelDev &lv = lev(g, level);
+    const Launch &L = g->ctx->L;
+    const int64_t n = vec_len(x);
+    launch_apply(L, lv, g->md, -1.0, g->lambda, x->d, b->d, r->d, 1);   // r = b - A x, constraint
+    interface_sum(g, lv, r->d);
+    int cur = S_RS, other = S_RS2;
+    launch_copy_dot(L, p->d, r->d, n, cur);                              // p = r; rs = r.r
+    scalar_sum(g, cur, 1);
+    for (int i = 0; i < steps; ++i) {
+        launch_apply(L, lv, g->md, 1.0, g->lambda, p->d, nullptr, Ap->d, 1);   // Ap = A p, constraint
+        interface_sum(g, lv, Ap->d);
+        launch_dot(L, p->d, Ap->d, n, S_PAP);
+        scalar_sum(g, S_PAP, 1);
+        launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs/pAp
+        scalar_sum(g, other, 1);
+        launch_cg_pupdate(L, p->d, r->d, n, other, cur);                       // beta = rs'/rs
+        std::swap(cur, other);
+    }
+}
+
+void coarse_setup(hmg_grid *g)
+{
+    need(g->has_op, "hmg_grid_set_operator must be called first");
+    const MeshTables &M = g->cur();
+    assemble_coarse_matrix(M, g->sigma.data(), g->lambda, g->cm);
+    if (!g->ctx) return;
+    hipStream_t s = g->ctx->stream;
+    g->c_rowptr.upload(g->cm.rowptr, s);
+    g->c_colidx.upload(g->cm.colidx, s);
+    g->c_val.upload(g->cm.val, s);
+    g->c_diag.upload(g->cm.diag, s);
+    g->c_interior.upload(g->cm.interior, s);
+    size_t n = (size_t)std::max<int64_t>(g->cm.n, 1);
+    g->c_b.alloc(n);
+    g->c_x.alloc(n);
+    g->c_r.alloc(n);
+    g->c_z.alloc(n);
+    g->c_p.alloc(n);
+    g->c_q.alloc(n);
+    g->c_u.alloc((size_t)M.nnodes);
+    g->cd.n = g->cm.n;
+    g->cd.rowptr = g->c_rowptr.p;
+    g->cd.colidx = g->c_colidx.p;
+    g->cd.val = g->c_val.p;
+    g->cd.diag = g->c_diag.p;
+    g->cd.interior = g->c_interior.p;
+    g->coarse_ready = true;
+}
+
+void coarse_pcg(hmg_grid *g)
+{
+    // Jacobi-PCG on (lambda M + K_sigma)[interior, interior] x = b to a relative residual of
+    // coarse_rtol; stands in for the reference's CHOLMOD solve (src/multigrid.jl:84).
+    hmg_ctx *c = g->ctx;
+    const Launch &L = c->L;
+    const CoarseDev &A = g->cd;
+    g->coarse_last_it = 0;
+    if (A.n == 0) return;
+    launch_coarse_init(L, A, g->c_b.p, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p);
+    double h[S_COUNT];
+    HIPCHK(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const double bb = h[S_C2];
+    if (!(bb > 0.0)) return;   // b == 0 -> x == 0
+    const double tol2 = c->coarse_rtol * c->coarse_rtol * bb;
+    int it = 0;
+    while (it < c->coarse_maxit) {
+        int chunk = std::min(c->coarse_check, c->coarse_maxit - it);
+        for (int q = 0; q < chunk; ++q) {
+            launch_coarse_spmv_dot(L, A, g->c_p.p, g->c_q.p);
+            launch_coarse_update(L, A, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p, g->c_q.p);
+            launch_coarse_pupdate(L, A, g->c_p.p, g->c_z.p);
+        }
+        it += chunk;
+        HIPCHK(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!(h[S_TMP] > tol2)) break;
+        if (!std::isfinite(h[S_TMP])) throw std::runtime_error("coarse PCG diverged (non-finite residual)");
+    }
+    g->coarse_last_it = it;
+}
+
+void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
+{
+    // ref: src/multigrid.jl:74-93
+    if (!g->coarse_ready) coarse_setup(g);
+    need(!g->exchange, "coarse solve on a partitioned grid goes through the host layer (gather to one rank)");
+    const LevelDev &lv = lev(g, 1);
+    const Launch &L = g->ctx->L;
+    interface_sum(g, lv, b1->d);
+    launch_gather_base(L, g->md, lv.ld, b1->d, g->c_u.p);
+    launch_coarse_gather_rhs(L, g->cd, g->c_u.p, g->c_b.p);
+    coarse_pcg(g);
+    launch_coarse_scatter_sol(L, g->cd, g->md.nnodes, g->c_x.p, g->c_u.p);
+    launch_scatter_base(L, g->md, lv.ld, g->c_u.p, x1->d);
+}
+
+void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
+{
+    // ref: src/multigrid.jl:73-119
+    hmg_vec **cur = st + 5 * (k - 1);
+    if (k == 1) {
+        coarse_solve(g, cur[1], cur[0]);
+        return;
+    }
+    hmg_vec **nxt = st + 5 * (k - 2);
+    const Launch &L = g->ctx->L;
+    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4]);
+    launch_apply(L, lev(g, k), g->md, -1.0, g->lambda, cur[0]->d, cur[1]->d, cur[2]->d, 1);   // local residual
+    launch_restrict(L, lev(g, k), lev(g, k - 1), g->md.ncells, cur[2]->d, nxt[1]->d);
+    launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
+    vcycle(g, k - 1, steps_coarse, steps_coarse, st);
+    launch_prolong_add(L, lev(g, k), lev(g, k - 1), g->md.ncells, nxt[0]->d, cur[0]->d);
+    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4]);
+}
+
+// ---- multi-GPU cut exchange -------------------------------------------------------------------
+void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);
+
+}  // namespace
+
+namespace {
+
+int64_t cut_doubles(const hmg_grid *g, const LevelDev &lv)
+{
+    return g->cut[0].nglobal * lv.nfi + g->cut[1].nglobal * lv.nei + g->cut[2].nglobal;
+}
+
+void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x)
+{
+    const Launch &L = g->ctx->L;
+    const int64_t n = cut_doubles(g, lv);
+    if (n == 0) return;
+    need(n <= g->ex_cap, "exchange buffer too small for this level");
+    launch_fill(L, g->ex_buf, n, 0.0);
+    int64_t off = 0;
+    const int per[3] = {lv.nfi, lv.nei, 1};
+    for (int k = 0; k < 3; ++k) {
+        if (g->cut[k].nentries && per[k])
+            launch_cut_pack(L, lv, k, g->cut[k].nentries, g->cut[k].gid.p, g->cut[k].cell_lid.p, g->cut[k].first.p,
+                            g->ex_buf + off, x, 0);
+        off += g->cut[k].nglobal * per[k];
+    }
+    if (g->exchange(g->ex_user, g->ex_buf, n) != 0) throw std::runtime_error("exchange callback failed");
+    off = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (g->cut[k].nentries && per[k])
+            launch_cut_pack(L, lv, k, g->cut[k].nentries, g->cut[k].gid.p, g->cut[k].cell_lid.p, g->cut[k].first.p,
+                            g->ex_buf + off, x, 1);
+        off += g->cut[k].nglobal * per[k];
+    }
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char *hmg_last_error(void) { return last_error().c_str(); }
+int hmg_version(void) { return 1; }
+
+int hmg_ctx_create(int device, void *stream, hmg_ctx **out)
+{
+    HMG_TRY
+    need(out != nullptr, "null out pointer");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        throw std::runtime_error("no HIP device available: libhmg_hip needs an MI355X (gfx950); there is no CPU fallback");
+    need(device >= 0 && device < ndev, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    std::unique_ptr<hmg_ctx> c(new hmg_ctx);
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->partials.alloc(4096);
+    c->scal.alloc(S_COUNT);
+    HIPCHK(hipMemsetAsync(c->scal.p, 0, S_COUNT * sizeof(double), c->stream));
+    c->L.stream = c->stream;
+    c->L.partials = c->partials.p;
+    c->L.scal = c->scal.p;
+    c->L.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->L.apply_variant = 1;
+    c->L.apply_threads = 0;
+    *out = c.release();
+    HMG_END
+}
+
+int hmg_ctx_destroy(hmg_ctx *ctx)
+{
+    HMG_TRY
+    if (ctx) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+    }
+    HMG_END
+}
+
+int hmg_ctx_sync(hmg_ctx *ctx)
+{
+    HMG_TRY
+    need(ctx != nullptr, "null ctx");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HMG_END
+}
+
+int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
+{
+    HMG_TRY
+    need(ctx && name, "null argument");
+    std::string n(name);
+    if (n == "apply_variant")
+        ctx->L.apply_variant = (int)value;
+    else if (n == "apply_threads")
+        ctx->L.apply_threads = (int)value;
+    else if (n == "coarse_maxit")
+        ctx->coarse_maxit = (int)value;
+    else if (n == "coarse_check")
+        ctx->coarse_check = std::max<int>(1, (int)value);
+    else
+        throw std::runtime_error("unknown option: " + n);
+    HMG_END
+}
+
+int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value)
+{
+    HMG_TRY
+    need(ctx && name, "null argument");
+    std::string n(name);
+    if (n == "coarse_rtol")
+        ctx->coarse_rtol = value;
+    else
+        throw std::runtime_error("unknown option: " + n);
+    HMG_END
+}
+
+void *hmg_ctx_scalar_bank(hmg_ctx *ctx) { return ctx ? (void *)ctx->scal.p : nullptr; }
+
+int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
+                    const int64_t *cells, hmg_grid **out)
+{
+    HMG_TRY
+    need(coords && cells && out, "null argument");
+    if (ctx) HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<hmg_grid> g(new hmg_grid);
+    g->ctx = ctx;
+    g->dim = dim;
+    g->nlevels = nlevels;
+    g->lt = build_level_tables(dim, nlevels);
+    build_mesh_tables(dim, nnodes, coords, ncells, cells, g->mesh_full);
+    hipStream_t s = ctx ? ctx->stream : nullptr;
+    g->ld.resize(nlevels);
+    for (int l = 0; l < nlevels; ++l) {
+        const LevelTables &T = g->lt[l];
+        g->lb.emplace_back(new LevelBufs);
+        LevelBufs &B = *g->lb.back();
+        if (ctx) {
+            B.meta.upload(T.meta, s);
+            B.ctab.upload(T.ctab, s);
+            B.hier2slot.upload(T.hier2slot, s);
+            B.par_a.upload(T.par_a, s);
+            B.par_b.upload(T.par_b, s);
+            B.rptr.upload(T.rptr, s);
+            B.ridx.upload(T.ridx, s);
+        }
+        LevelDev &D = g->ld[l];
+        D.dim = T.dim;
+        D.level = T.level;
+        D.m = T.m;
+        D.nf = T.nf;
+        D.ld = T.ld;
+        D.ncorner = T.ncorner;
+        D.nedge = T.nedge;
+        D.nface = T.nface;
+        D.nei = T.nei;
+        D.nfi = T.nfi;
+        D.nint = T.nint;
+        D.off_edge = T.off_edge;
+        D.off_face = T.off_face;
+        D.off_int = T.off_int;
+        D.ncls = T.ncls;
+        D.ndir = T.ndir;
+        D.nterm = T.nterm;
+        D.lds_g0 = T.lds_g0;
+        D.lds_g1 = T.lds_g1;
+        D.nf_coarse = l > 0 ? g->lt[l - 1].nf : 0;
+        D.meta = B.meta.p;
+        D.ctab = B.ctab.p;
+        D.hier2slot = B.hier2slot.p;
+        D.par_a = B.par_a.p;
+        D.par_b = B.par_b.p;
+        D.rptr = B.rptr.p;
+        D.ridx = B.ridx.p;
+    }
+    upload_mesh(g.get());
+    *out = g.release();
+    HMG_END
+}
+
+int hmg_grid_destroy(hmg_grid *grid)
+{
+    HMG_TRY
+    if (grid) {
+        if (grid->ctx) (void)hipStreamSynchronize(grid->ctx->stream);
+        delete grid;
+    }
+    HMG_END
+}
+
+int hmg_grid_set_operator(hmg_grid *g, const double *sigma, double lambda)
+{
+    HMG_TRY
+    need(g && sigma, "null argument");
+    g->sigma.assign(sigma, sigma + (size_t)g->mesh_full.ncells * g->dim);
+    g->lambda = lambda;
+    g->has_op = true;
+    upload_operator(g);
+    HMG_END
+}
+
+int hmg_grid_set_lambda(hmg_grid *g, double lambda)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    g->lambda = lambda;
+    g->coarse_ready = false;
+    HMG_END
+}
+
+int hmg_grid_shrink(hmg_grid *g, int64_t ncells_prefix, int64_t nnodes_prefix)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    need(!g->exchange, "shrink on a partitioned grid is not supported yet");
+    restrict_mesh_tables(g->mesh_full, ncells_prefix, nnodes_prefix, g->mesh);
+    g->shrunk = true;
+    upload_mesh(g);
+    if (g->has_op) upload_operator(g);
+    HMG_END
+}
+
+int64_t hmg_grid_ncells(const hmg_grid *g) { return g ? g->md.ncells : -1; }
+int64_t hmg_grid_nnodes(const hmg_grid *g) { return g ? g->md.nnodes : -1; }
+int hmg_grid_nlevels(const hmg_grid *g) { return g ? g->nlevels : -1; }
+int64_t hmg_grid_nf(const hmg_grid *g, int level)
+{
+    return (g && level >= 1 && level <= g->nlevels) ? g->lt[level - 1].nf : -1;
+}
+int64_t hmg_grid_ld(const hmg_grid *g, int level)
+{
+    return (g && level >= 1 && level <= g->nlevels) ? g->lt[level - 1].ld : -1;
+}
+
+int hmg_grid_table_i32(const hmg_grid *g, int level, const char *which, int32_t *out, int64_t cap, int64_t *count)
+{
+    HMG_TRY
+    need(g && which && count, "null argument");
+    std::string w(which);
+    std::vector<int32_t> tmp;
+    const std::vector<int32_t> *src = nullptr;
+    if (w == "dmask" || w == "dupmask") {
+        const auto &m = w == "dmask" ? g->cur().dmask : g->cur().dupmask;
+        tmp.assign(m.begin(), m.end());
+        src = &tmp;
+    } else if (w == "face_pairs") {
+        src = &g->cur().face_pairs;
+    } else if (w == "edge_ptr") {
+        src = &g->cur().edge_ptr;
+    } else if (w == "edge_ent") {
+        src = &g->cur().edge_ent;
+    } else if (w == "node_ptr") {
+        src = &g->cur().node_ptr;
+    } else if (w == "node_ent") {
+        src = &g->cur().node_ent;
+    } else if (w == "node_first") {
+        src = &g->cur().node_first;
+    } else if (w == "coarse_rowptr") {
+        src = &g->cm.rowptr;
+    } else if (w == "coarse_colidx") {
+        src = &g->cm.colidx;
+    } else if (w == "interior_nodes") {
+        const MeshTables &M = g->cur();
+        for (int64_t i = 0; i < M.nnodes; ++i)
+            if (!M.node_on_boundary[i] && M.node_first[i] >= 0) tmp.push_back((int32_t)i);
+        src = &tmp;
+    } else {
+        need(level >= 1 && level <= g->nlevels, "level out of range");
+        const LevelTables &T = g->lt[level - 1];
+        if (w == "hier2slot")
+            src = &T.hier2slot;
+        else if (w == "slot_ijk")
+            src = &T.slot_ijk;
+        else if (w == "par_a")
+            src = &T.par_a;
+        else if (w == "par_b")
+            src = &T.par_b;
+        else if (w == "rptr")
+            src = &T.rptr;
+        else if (w == "ridx")
+            src = &T.ridx;
+        else if (w == "slot_cls") {
+            tmp.assign(T.slot_cls.begin(), T.slot_cls.end());
+            src = &tmp;
+        } else if (w == "layout") {
+            tmp = {T.nf, T.ld, T.ncorner, T.nedge, T.nface, T.nei, T.nfi, T.nint, T.off_edge, T.off_face, T.off_int,
+                   T.ncls, T.ndir, T.nterm, T.lds_g0, T.lds_g1, T.m};
+            src = &tmp;
+        } else
+            throw std::runtime_error("unknown i32 table: " + w);
+    }
+    *count = (int64_t)src->size();
+    if (out) {
+        need(cap >= *count, "output buffer too small");
+        std::copy(src->begin(), src->end(), out);
+    }
+    HMG_END
+}
+
+int hmg_grid_table_f64(const hmg_grid *g, int level, const char *which, double *out, int64_t cap, int64_t *count)
+{
+    HMG_TRY
+    need(g && which && count, "null argument");
+    std::string w(which);
+    const std::vector<double> *src = nullptr;
+    if (w == "coef")
+        src = &g->coef;
+    else if (w == "ctab") {
+        need(level >= 1 && level <= g->nlevels, "level out of range");
+        src = &g->lt[level - 1].ctab;
+    } else if (w == "coarse_val")
+        src = &g->cm.val;
+    else
+        throw std::runtime_error("unknown f64 table: " + w);
+    *count = (int64_t)src->size();
+    if (out) {
+        need(cap >= *count, "output buffer too small");
+        std::copy(src->begin(), src->end(), out);
+    }
+    HMG_END
+}
+
+// ---- vectors ----------------------------------------------------------------------------------
+int hmg_vec_create(hmg_grid *g, int level, hmg_vec **out)
+{
+    HMG_TRY
+    need(g && out, "null argument");
+    const LevelDev &lv = lev(g, level);
+    HIPCHK(hipSetDevice(g->ctx->device));
+    std::unique_ptr<hmg_vec> v(new hmg_vec);
+    v->g = g;
+    v->level = level;
+    v->own = true;
+    v->alloc_cells = g->md.ncells;
+    size_t bytes = sizeof(double) * (size_t)lv.ld * (size_t)g->md.ncells;
+    HIPCHK(hipMalloc((void **)&v->d, bytes));
+    HIPCHK(hipMemsetAsync(v->d, 0, bytes, g->ctx->stream));
+    *out = v.release();
+    HMG_END
+}
+
+int hmg_vec_wrap(hmg_grid *g, int level, void *device_ptr, hmg_vec **out)
+{
+    HMG_TRY
+    need(g && out && device_ptr, "null argument");
+    (void)lev(g, level);
+    std::unique_ptr<hmg_vec> v(new hmg_vec);
+    v->g = g;
+    v->level = level;
+    v->own = false;
+    v->alloc_cells = g->md.ncells;
+    v->d = (double *)device_ptr;
+    *out = v.release();
+    HMG_END
+}
+
+int hmg_vec_destroy(hmg_vec *v)
+{
+    HMG_TRY
+    if (v) {
+        if (v->own && v->d) {
+            (void)hipStreamSynchronize(v->g->ctx->stream);
+            (void)hipFree(v->d);
+        }
+        delete v;
+    }
+    HMG_END
+}
+
+void *hmg_vec_device_ptr(hmg_vec *v) { return v ? (void *)v->d : nullptr; }
+
+static const int64_t STAGE_DOUBLES = (int64_t)32 << 20;   // 256 MiB staging chunks
+
+int hmg_vec_upload(hmg_vec *v, const double *host)
+{
+    HMG_TRY
+    need(v && host, "null argument");
+    hmg_grid *g = v->g;
+    const LevelDev &lv = lev(g, v->level);
+    const int64_t ncells = g->md.ncells;
+    int64_t cells_per = std::max<int64_t>(1, STAGE_DOUBLES / lv.nf);
+    cells_per = std::min(cells_per, ncells);
+    DevBuf<double> stage;
+    stage.alloc((size_t)cells_per * lv.nf);
+    for (int64_t c0 = 0; c0 < ncells; c0 += cells_per) {
+        int64_t nc = std::min(cells_per, ncells - c0);
+        HIPCHK(hipMemcpyAsync(stage.p, host + c0 * lv.nf, sizeof(double) * nc * lv.nf, hipMemcpyHostToDevice,
+                              g->ctx->stream));
+        launch_permute(g->ctx->L, lv, nc, stage.p, v->d + c0 * lv.ld, 1);
+        HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    }
+    HMG_END
+}
+
+int hmg_vec_download(hmg_vec *v, double *host)
+{
+    HMG_TRY
+    need(v && host, "null argument");
+    hmg_grid *g = v->g;
+    const LevelDev &lv = lev(g, v->level);
+    const int64_t ncells = g->md.ncells;
+    int64_t cells_per = std::max<int64_t>(1, STAGE_DOUBLES / lv.nf);
+    cells_per = std::min(cells_per, ncells);
+    DevBuf<double> stage;
+    stage.alloc((size_t)cells_per * lv.nf);
+    for (int64_t c0 = 0; c0 < ncells; c0 += cells_per) {
+        int64_t nc = std::min(cells_per, ncells - c0);
+        launch_permute(g->ctx->L, lv, nc, v->d + c0 * lv.ld, stage.p, 0);
+        HIPCHK(hipMemcpyAsync(host + c0 * lv.nf, stage.p, sizeof(double) * nc * lv.nf, hipMemcpyDeviceToHost,
+                              g->ctx->stream));
+        HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    }
+    HMG_END
+}
+
+int hmg_vec_fill(hmg_vec *v, double value)
+{
+    HMG_TRY
+    need(v != nullptr, "null vector");
+    launch_fill(v->g->ctx->L, v->d, vec_len(v), value);
+    HMG_END
+}
+
+int hmg_vec_fill_random(hmg_vec *v, uint64_t seed, int64_t cell_offset)
+{
+    HMG_TRY
+    need(v != nullptr, "null vector");
+    launch_fill_random(v->g->ctx->L, lev(v->g, v->level), v->g->md.ncells, v->d, seed, cell_offset);
+    HMG_END
+}
+
+int hmg_vec_copy(hmg_vec *dst, hmg_vec *src)
+{
+    HMG_TRY
+    need(dst && src, "null vector");
+    check_vec(dst->g, dst->level, src, "src");
+    launch_copy(dst->g->ctx->L, dst->d, src->d, vec_len(dst));
+    HMG_END
+}
+
+int hmg_vec_axpy(double alpha, hmg_vec *x, hmg_vec *y)
+{
+    HMG_TRY
+    need(x && y, "null vector");
+    check_vec(y->g, y->level, x, "x");
+    launch_axpy(y->g->ctx->L, alpha, x->d, y->d, vec_len(y));
+    HMG_END
+}
+
+int hmg_vec_xpby(hmg_vec *r, double beta, hmg_vec *p)
+{
+    HMG_TRY
+    need(r && p, "null vector");
+    check_vec(p->g, p->level, r, "r");
+    launch_xpby(p->g->ctx->L, r->d, beta, p->d, vec_len(p));
+    HMG_END
+}
+
+static double read_scalar(hmg_ctx *c, int slot)
+{
+    double h = 0.0;
+    HIPCHK(hipMemcpyAsync(&h, c->scal.p + slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return h;
+}
+
+int hmg_vec_dot(hmg_vec *x, hmg_vec *y, double *out)
+{
+    HMG_TRY
+    need(x && y && out, "null argument");
+    check_vec(x->g, x->level, y, "y");
+    launch_dot(x->g->ctx->L, x->d, y->d, vec_len(x), S_TMP);
+    scalar_sum(x->g, S_TMP, 1);
+    *out = read_scalar(x->g->ctx, S_TMP);
+    HMG_END
+}
+
+int hmg_vec_norm_unique(hmg_vec *r, double *out)
+{
+    HMG_TRY
+    need(r && out, "null argument");
+    need(!r->g->exchange, "norm_unique on a partitioned grid goes through the host layer");
+    launch_norm2_unique(r->g->ctx->L, lev(r->g, r->level), r->g->md, r->d, S_TMP);
+    *out = std::sqrt(read_scalar(r->g->ctx, S_TMP));
+    HMG_END
+}
+
+// ---- primitives ---------------------------------------------------------------------------------
+int hmg_apply(hmg_grid *g, int level, double alpha, hmg_vec *x, hmg_vec *y)
+{
+    HMG_TRY
+    need(g && g->has_op, "operator not set");
+    check_vec(g, level, x, "x");
+    check_vec(g, level, y, "y");
+    need(x->d != y->d, "x and y must not alias");
+    launch_apply(g->ctx->L, lev(g, level), g->md, alpha, g->lambda, x->d, y->d, y->d, 0);
+    HMG_END
+}
+
+int hmg_residual(hmg_grid *g, int level, hmg_vec *x, hmg_vec *b, hmg_vec *r)
+{
+    HMG_TRY
+    need(g && g->has_op, "operator not set");
+    check_vec(g, level, x, "x");
+    check_vec(g, level, b, "b");
+    check_vec(g, level, r, "r");
+    need(x->d != r->d, "x and r must not alias");
+    launch_apply(g->ctx->L, lev(g, level), g->md, -1.0, g->lambda, x->d, b->d, r->d, 1);
+    HMG_END
+}
+
+int hmg_constraint(hmg_grid *g, int level, hmg_vec *x)
+{
+    HMG_TRY
+    check_vec(g, level, x, "x");
+    launch_mask(g->ctx->L, lev(g, level), g->md, x->d, 0);
+    HMG_END
+}
+
+int hmg_interface_sum(hmg_grid *g, int level, hmg_vec *x)
+{
+    HMG_TRY
+    check_vec(g, level, x, "x");
+    interface_sum(g, lev(g, level), x->d);
+    HMG_END
+}
+
+int hmg_zero_duplicates(hmg_grid *g, int level, hmg_vec *x)
+{
+    HMG_TRY
+    check_vec(g, level, x, "x");
+    launch_mask(g->ctx->L, lev(g, level), g->md, x->d, 1);
+    HMG_END
+}
+
+int hmg_restrict(hmg_grid *g, int level_fine, hmg_vec *r_fine, hmg_vec *b_coarse)
+{
+    HMG_TRY
+    need(g && level_fine >= 2, "restriction needs level_fine >= 2");
+    check_vec(g, level_fine, r_fine, "r_fine");
+    check_vec(g, level_fine - 1, b_coarse, "b_coarse");
+    launch_restrict(g->ctx->L, lev(g, level_fine), lev(g, level_fine - 1), g->md.ncells, r_fine->d, b_coarse->d);
+    HMG_END
+}
+
+int hmg_prolong_add(hmg_grid *g, int level_fine, hmg_vec *x_coarse, hmg_vec *x_fine)
+{
+    HMG_TRY
+    need(g && level_fine >= 2, "prolongation needs level_fine >= 2");
+    check_vec(g, level_fine, x_fine, "x_fine");
+    check_vec(g, level_fine - 1, x_coarse, "x_coarse");
+    launch_prolong_add(g->ctx->L, lev(g, level_fine), lev(g, level_fine - 1), g->md.ncells, x_coarse->d, x_fine->d);
+    HMG_END
+}
+
+int hmg_gather_base(hmg_grid *g, hmg_vec *v1, double *host_u)
+{
+    HMG_TRY
+    need(g && host_u, "null argument");
+    check_vec(g, 1, v1, "v1");
+    DevBuf<double> u;
+    u.alloc((size_t)g->md.nnodes);
+    launch_gather_base(g->ctx->L, g->md, lev(g, 1).ld, v1->d, u.p);
+    HIPCHK(hipMemcpyAsync(host_u, u.p, sizeof(double) * g->md.nnodes, hipMemcpyDeviceToHost, g->ctx->stream));
+    HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    HMG_END
+}
+
+int hmg_scatter_base(hmg_grid *g, const double *host_u, hmg_vec *v1)
+{
+    HMG_TRY
+    need(g && host_u, "null argument");
+    check_vec(g, 1, v1, "v1");
+    DevBuf<double> u;
+    u.alloc((size_t)g->md.nnodes);
+    HIPCHK(hipMemcpyAsync(u.p, host_u, sizeof(double) * g->md.nnodes, hipMemcpyHostToDevice, g->ctx->stream));
+    launch_scatter_base(g->ctx->L, g->md, lev(g, 1).ld, u.p, v1->d);
+    HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    HMG_END
+}
+
+// ---- fused fast path ----------------------------------------------------------------------------
+int hmg_smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap)
+{
+    HMG_TRY
+    need(g && g->has_op, "operator not set");
+    check_vec(g, level, x, "x");
+    check_vec(g, level, b, "b");
+    check_vec(g, level, r, "r");
+    check_vec(g, level, p, "p");
+    check_vec(g, level, Ap, "Ap");
+    smooth(g, level, steps, x, b, r, p, Ap);
+    HMG_END
+}
+
+int hmg_coarse_setup(hmg_grid *g)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    coarse_setup(g);
+    HMG_END
+}
+
+int hmg_coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
+{
+    HMG_TRY
+    need(g && g->has_op, "operator not set");
+    check_vec(g, 1, b1, "b1");
+    check_vec(g, 1, x1, "x1");
+    coarse_solve(g, b1, x1);
+    HMG_END
+}
+
+int hmg_coarse_last_iterations(const hmg_grid *g) { return g ? g->coarse_last_it : -1; }
+
+int hmg_vcycle(hmg_grid *g, int top_level, int steps, int steps_coarse, hmg_vec **states)
+{
+    HMG_TRY
+    need(g && g->has_op && states, "null argument or operator not set");
+    need(top_level >= 1 && top_level <= g->nlevels, "top_level out of range");
+    for (int l = 1; l <= top_level; ++l)
+        for (int q = 0; q < 5; ++q) check_vec(g, l, states[5 * (l - 1) + q], "states[]");
+    vcycle(g, top_level, steps, steps_coarse, states);
+    HMG_END
+}
+
+// ---- multi-GPU hooks ------------------------------------------------------------------------------
+static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const int64_t *gid, const int32_t *cell_lid)
+{
+    CutKind &c = g->cut[k];
+    c.nglobal = nglobal;
+    c.nentries = n;
+    std::vector<int64_t> hg(gid, gid + n);
+    std::vector<int32_t> hc(cell_lid, cell_lid + n);
+    std::vector<uint8_t> first(n, 0);
+    std::unordered_map<int64_t, int> seen;
+    for (int64_t i = 0; i < n; ++i) {
+        need(hg[i] >= 0 && hg[i] < nglobal, "cut id out of range");
+        need((hc[i] >> 3) >= 0 && (hc[i] >> 3) < g->md.ncells, "cut entry references a cell outside the grid");
+        if (seen.emplace(hg[i], 1).second) first[i] = 1;
+    }
+    c.gid.upload(hg, g->ctx->stream);
+    c.cell_lid.upload(hc, g->ctx->stream);
+    c.first.upload(first, g->ctx->stream);
+}
+
+int hmg_grid_set_cut(hmg_grid *g, int64_t ngf, int64_t nge, int64_t ngn, int64_t nlf, const int64_t *face_gid,
+                     const int32_t *face_cell_lid, int64_t nle, const int64_t *edge_gid, const int32_t *edge_cell_lid,
+                     int64_t nln, const int64_t *node_gid, const int32_t *node_cell_lid)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    set_cut_kind(g, 0, ngf, nlf, face_gid, face_cell_lid);
+    set_cut_kind(g, 1, nge, nle, edge_gid, edge_cell_lid);
+    set_cut_kind(g, 2, ngn, nln, node_gid, node_cell_lid);
+    HMG_END
+}
+
+int hmg_grid_set_exchange(hmg_grid *g, hmg_exchange_fn exchange, hmg_exchange_fn scalar_sum_fn, void *user,
+                          void *device_exchange_buf, int64_t exchange_buf_doubles)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    g->exchange = exchange;
+    g->scalar_sum = scalar_sum_fn;
+    g->ex_user = user;
+    g->ex_buf = (double *)device_exchange_buf;
+    g->ex_cap = exchange_buf_doubles;
+    HMG_END
+}
+
+int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *g, int level)
+{
+    if (!g || level < 1 || level > g->nlevels) return -1;
+    return cut_doubles(g, g->ld[level - 1]);
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Device-side view of the tables and the kernel launch API (implemented in hmg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace hmg {
+
+struct LevelDev {
+    int dim, level, m;
+    int nf, ld;
+    int ncorner, nedge, nface;
+    int nei, nfi, nint;
+    int off_edge, off_face, off_int;
+    int ncls, ndir, nterm;
+    int lds_g0, lds_g1;
+    int nf_coarse;                 // nf of level-1 (0 on level 1)
+    const uint64_t *meta;          // [nf]
+    const double *ctab;            // [ncls*ndir*nterm]
+    const int32_t *hier2slot;      // [nf]
+    const int32_t *par_a, *par_b;  // [nf]     (level > 1)
+    const int32_t *rptr, *ridx;    // [nf_coarse+1], [..] (level > 1)
+};
+
+struct MeshDev {
+    int dim;
+    int64_t ncells, nnodes;
+    const int32_t *cells;        // (dim+1)*ncells
+    const int32_t *face_pairs;   // 3*nfacepairs
+    int64_t nfacepairs;
+    const int32_t *edge_ptr, *edge_ent;
+    int64_t nsharededges;
+    const int32_t *node_ptr, *node_ent;
+    int64_t nsharednodes;
+    const int32_t *node_first;   // nnodes
+    const uint16_t *dmask, *dupmask;
+    const double *coef;          // 8 per cell
+};
+
+struct CoarseDev {
+    int64_t n;
+    const int32_t *rowptr, *colidx;
+    const double *val, *diag;
+    const int32_t *interior;     // n
+};
+
+// scalar bank slots (device doubles)
+enum { S_RS = 0, S_PAP = 1, S_RS2 = 2, S_TMP = 3, S_C0 = 4, S_C1 = 5, S_C2 = 6, S_C3 = 7, S_COUNT = 16 };
+
+struct Launch {
+    hipStream_t stream;
+    double *partials;     // >= 4096 doubles
+    double *scal;         // S_COUNT doubles
+    int num_cu;
+    int apply_variant;    // 0 generic, 1 persistent register-meta
+    int apply_threads;    // 0 = auto
+};
+
+// out = (src ? src : 0) + alpha * A x, then (use_mask) zero Dirichlet DOFs.  src may alias out.
+void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
+                  const double *x, const double *src, double *out, int use_mask);
+size_t apply_lds_bytes(const LevelDev &lv);
+
+void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x);
+void launch_mask(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which /*0 dmask,1 dupmask*/);
+void launch_restrict(const Launch &L, const LevelDev &fine, const LevelDev &coarse, int64_t ncells,
+                     const double *rf, double *bc);
+void launch_prolong_add(const Launch &L, const LevelDev &fine, const LevelDev &coarse, int64_t ncells,
+                        const double *xc, double *xf);
+
+void launch_fill(const Launch &L, double *x, int64_t n, double v);
+void launch_copy(const Launch &L, double *dst, const double *src, int64_t n);
+void launch_axpy(const Launch &L, double a, const double *x, double *y, int64_t n);
+void launch_xpby(const Launch &L, const double *r, double b, double *p, int64_t n);
+// scal[slot] = sum x*y   (deterministic two-stage reduction)
+void launch_dot(const Launch &L, const double *x, const double *y, int64_t n, int slot);
+// scal[slot] = sum over first copies only of x*x
+void launch_norm2_unique(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *x, int slot);
+// p = r; scal[slot] = r.r
+void launch_copy_dot(const Launch &L, double *p, const double *r, int64_t n, int slot);
+// alpha = scal[s_num]/scal[s_den]; x += alpha p; r -= alpha q; scal[s_out] = r.r
+void launch_cg_update(const Launch &L, double *x, double *r, const double *p, const double *q, int64_t n,
+                      int s_num, int s_den, int s_out);
+// beta = scal[s_num]/scal[s_den]; p = r + beta p; afterwards scal[s_den] = scal[s_num]
+void launch_cg_pupdate(const Launch &L, double *p, const double *r, int64_t n, int s_num, int s_den);
+
+void launch_gather_base(const Launch &L, const MeshDev &mesh, int ld1, const double *v1, double *u);
+void launch_scatter_base(const Launch &L, const MeshDev &mesh, int ld1, const double *u, double *v1);
+
+void launch_permute(const Launch &L, const LevelDev &lv, int64_t ncells, const double *src, double *dst,
+                    int to_storage);
+void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, double *x, uint64_t seed,
+                        int64_t cell_offset);
+
+// Jacobi-PCG pieces for the level-1 system
+void launch_coarse_gather_rhs(const Launch &L, const CoarseDev &A, const double *u, double *b);
+void launch_coarse_scatter_sol(const Launch &L, const CoarseDev &A, int64_t nnodes, const double *x, double *u);
+void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z,
+                        double *p);   // x=0,r=b,z=r/d,p=z, scal[S_C0]=r.z, scal[S_C2]=b.b
+void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q);  // S_C1 = p.q
+void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
+                          const double *q);   // alpha=C0/C1; S_C3 = r.z (new); S_TMP = r.r
+void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z);   // beta=C3/C0; C0=C3
+
+// multi-GPU cut exchange: unpack = 0 packs buf[gid] <- x (first local copy), 1 writes x <- buf[gid]
+void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nentries, const int64_t *gid,
+                     const int32_t *cell_lid, const uint8_t *first, double *buf, double *x, int unpack);
+
+}  // namespace hmg

@@ -1,0 +1,121 @@
+// Host-side data model of the MI355X implicit-grid multigrid library.
+//
+// Nothing in here is a translation of the reference's Julia containers: the reference keeps
+// per-level CSC matrices and ascending node-id lists (src/build_local_operators.jl,
+// src/multilevel_reference.jl); this library keeps, per level, (1) an *entity-major* storage
+// order of a cell's DOFs so that every shared face / edge of two cells is one contiguous,
+// identically ordered run in both columns, and (2) a 15-point (3D) / 7-point (2D) lattice stencil
+// in "class" form (one coefficient row per entity of the reference simplex).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace hmg {
+
+// ---------------------------------------------------------------------------------------------
+// Per-level tables of the refined reference simplex.
+// ---------------------------------------------------------------------------------------------
+struct LevelTables {
+    int dim = 0;
+    int level = 0;       // 1-based, as in the reference
+    int m = 0;           // lattice intervals per edge: 2^(level-1)
+    int nf = 0;          // DOFs per coarse cell (nodes of the refined reference simplex)
+    int ld = 0;          // column stride of a level vector in doubles
+    int ncorner = 0, nedge = 0, nface = 0;
+    int nei = 0, nfi = 0, nint = 0;             // interior DOFs per edge / face / cell
+    int off_edge = 0, off_face = 0, off_int = 0; // storage offsets of the entity segments
+
+    // hierarchical (reference / API) node id <-> storage slot
+    std::vector<int32_t> hier2slot, slot2hier;
+    // lattice coordinates (i,j,k) of every storage slot (k = 0 in 2D)
+    std::vector<int32_t> slot_ijk;
+    // entity class of every slot: 0 interior, 1..nface faces, then edges, then corners
+    std::vector<uint8_t> slot_cls;
+    // packed per-slot stencil addressing word (see pack_meta)
+    std::vector<uint64_t> meta;
+    int lds_g0 = 0, lds_g1 = 0;   // LDS guard entries in front of / behind the lattice image
+
+    // stencil in class form: ctab[(cls*ndir + dir)*nterm + term]
+    int ncls = 0, ndir = 0, nterm = 0;
+    std::vector<double> ctab;
+
+    // transfer operators between level-1 (coarse) and this level (fine); empty on level 1.
+    // prolongation: fine slot <- 0.5*coarse[pa] + 0.5*coarse[pb] (pa == pb: identity row);
+    // pa is the parent with the smaller hierarchical id (the reference's CSC column order).
+    std::vector<int32_t> par_a, par_b;
+    // restriction (gather form): coarse slot c sums fine slots ridx[rptr[c]..rptr[c+1]) in
+    // ascending fine hierarchical id; the first entry is the identity row (weight 1), the rest 0.5.
+    std::vector<int32_t> rptr, ridx;
+};
+
+inline uint64_t pack_meta(uint32_t L, uint32_t len, uint32_t cls, uint32_t A, uint32_t B)
+{
+    return (uint64_t)L | ((uint64_t)len << 16) | ((uint64_t)cls << 24) | ((uint64_t)A << 32) |
+           ((uint64_t)B << 48);
+}
+
+// Builds tables for levels 1..nlevels of the reference simplex of dimension dim (2 or 3).
+// Numbering contract (normative, from the reference): src/multilevel_reference.jl:9-13,41-61,
+// src/tet/refine.jl:16-21, src/tri/refine.jl:21-25, src/sparse_graph.jl:20-48.
+std::vector<LevelTables> build_level_tables(int dim, int nlevels);
+
+// Stencil direction list: offsets (di,dj,dk); entry 0 is the node itself.
+int stencil_dirs(int dim, const int (**dirs)[3]);
+
+// ---------------------------------------------------------------------------------------------
+// Base-mesh tables.
+// ---------------------------------------------------------------------------------------------
+struct MeshTables {
+    int dim = 0;
+    int64_t nnodes = 0, ncells = 0;
+    std::vector<double> coords;    // dim * nnodes (node-major)
+    std::vector<int32_t> cells;    // (dim+1) * ncells, 0-based, sorted per cell
+
+    // shared faces (3D): exactly two copies each. Packed: cellA, cellB, (lfA | lfB<<4)
+    std::vector<int32_t> face_pairs;   // 3 ints per shared face
+    // shared edges / nodes in CSR form; entry = cell * 8 + local id
+    std::vector<int32_t> edge_ptr, edge_ent;
+    std::vector<int32_t> node_ptr, node_ent;
+    // every base node: first listed copy (cell*8 + local node), for the level-1 gather
+    std::vector<int32_t> node_first;
+    // per cell: Dirichlet entity bitmask and "not the first copy" bitmask; bit = cls-1
+    std::vector<uint16_t> dmask, dupmask;
+    // boundary (Dirichlet) base nodes flag
+    std::vector<uint8_t> node_on_boundary;
+
+    // cell geometry: detJ and Jinv = inv(J') (column-major dim x dim)
+    std::vector<double> detj, jinv;
+};
+
+// cells_1based: (dim+1) x ncells, 1-based, each column ascending (reference contract,
+// src/implicit_fine_grid.jl:14).
+void build_mesh_tables(int dim, int64_t nnodes, const double *coords, int64_t ncells,
+                       const int64_t *cells_1based, MeshTables &out);
+
+// Recomputes Dirichlet masks / boundary flags for the mesh restricted to the first
+// `ncells_prefix` cells (domain shrink, ref: src/examples/homogenized_coefficients.jl:309-316),
+// and rebuilds the shared-entity lists for that prefix.
+void restrict_mesh_tables(const MeshTables &full, int64_t ncells_prefix, int64_t nnodes_prefix,
+                          MeshTables &out);
+
+// Per-cell operator coefficients: coef[cell*8 + t] = |J| * P_t for the unique entries of
+// P = J^-1 diag(sigma) J^-T (3D: 11,12,13,22,23,33; 2D: 11,12,22), then |J| at t = nterm-1.
+// ref: src/apply_local_operators.jl:101-118.
+void build_cell_coefficients(const MeshTables &mesh, const double *sigma, std::vector<double> &coef);
+
+// Coarse (level-1) operator lambda*M + K_sigma on the base mesh, interior rows/cols only, CSR.
+// ref: src/examples/homogenized_coefficients.jl:358-402 (assemble_checkerboard), src/grid.jl:176-202.
+struct CoarseMatrix {
+    int64_t n = 0;                      // interior unknowns
+    std::vector<int32_t> interior;      // interior node ids (ascending)
+    std::vector<int32_t> node2int;      // base node -> interior index or -1
+    std::vector<int32_t> rowptr, colidx;
+    std::vector<double> val, diag;
+};
+void assemble_coarse_matrix(const MeshTables &mesh, const double *sigma, double lambda,
+                            CoarseMatrix &out);
+
+std::string &last_error();
+
+}  // namespace hmg

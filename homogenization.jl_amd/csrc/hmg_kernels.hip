@@ -1,0 +1,1036 @@
+// HIP kernels for gfx950 (MI355X): per-cell lattice-stencil operator apply, interface sum,
+// Dirichlet / duplicate masks, level transfer, fused CG vector kernels, level-1 gather/scatter and
+// a Jacobi-PCG for the coarse system.  Wave = 64 lanes everywhere.
+//
+// Reference behaviour reproduced (file:line in the reference checkout):
+//   k_apply*            src/apply_local_operators.jl:85-133 (+ :7-27 residual, + constraint mask)
+//   k_iface_*           src/implicit_fine_grid.jl:209-328   (copies summed in ascending cell order)
+//   k_mask              src/implicit_fine_grid.jl:94-139 / :334-386
+//   k_restrict/prolong  src/interpolation.jl:52-74
+//   k_cg_*, k_dot*      src/multigrid.jl:46-71
+//   k_gather/scatter    src/implicit_fine_grid.jl:148-202
+#include "hmg_device.hpp"
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace hmg {
+
+#define HMG_HIP_CHECK(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + \
+                                     __FILE__ + ":" + std::to_string(__LINE__));                \
+    } while (0)
+
+static inline void check_launch() { HMG_HIP_CHECK(hipGetLastError()); }
+
+constexpr int WSZ = 232;   // LDS doubles reserved for the class weight table (>= 15*15, 16-B multiple)
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// all threads of the block call; result valid in thread 0. red: >= blockDim/64 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) s += red[i];
+    }
+    __syncthreads();
+    return s;
+}
+
+__global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ partials, int n, double *scal, int slot)
+{
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    double s = block_sum(v, red);
+    if (threadIdx.x == 0) scal[slot] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// operator apply
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__device__ __forceinline__ double stencil_eval(const double *__restrict__ w, const double *__restrict__ p, int len,
+                                               int A, int B)
+{
+    double acc = w[0] * p[0];
+    acc += w[1] * p[1];
+    acc += w[2] * p[-1];
+    acc += w[3] * p[len - 1];
+    acc += w[4] * p[-len];
+    acc += w[5] * p[len];
+    acc += w[6] * p[-len - 1];
+    if (DIM == 3) {
+        const double *pu = p + A;
+        const double *pd = p - B;
+        acc += w[7] * pu[-len];
+        acc += w[8] * pd[len + 1];
+        acc += w[9] * pu[-1];
+        acc += w[10] * pd[1];
+        acc += w[11] * pu[0];
+        acc += w[12] * pd[0];
+        acc += w[13] * pu[1 - len];
+        acc += w[14] * pd[len];
+    }
+    return acc;
+}
+
+template <int DIM>
+__device__ __forceinline__ void cell_scales(const double *__restrict__ cc, double alpha, double lambda, double *s)
+{
+    constexpr int NTERM = DIM == 3 ? 7 : 4;
+#pragma unroll
+    for (int t = 0; t < NTERM - 1; ++t) s[t] = alpha * cc[t];
+    s[NTERM - 1] = alpha * lambda * cc[NTERM - 1];
+}
+
+// Generic variant: one workgroup per coarse cell, addressing words re-read from L2 per cell.
+template <int DIM, int NT>
+__global__ void __launch_bounds__(NT)
+k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, double alpha, double lambda,
+        const double *__restrict__ x, const double *src, double *out, int use_mask)
+{
+    constexpr int NDIR = DIM == 3 ? 15 : 7;
+    constexpr int NTERM = DIM == 3 ? 7 : 4;
+    extern __shared__ double smem[];
+    double *W = smem;
+    double *xs = smem + WSZ + lv.lds_g0;
+    const int tid = threadIdx.x;
+    const int64_t cell = blockIdx.x;
+    const int nf = lv.nf;
+
+    double s[NTERM];
+    cell_scales<DIM>(coef + cell * 8, alpha, lambda, s);
+    for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
+        const double *c = lv.ctab + (size_t)idx * NTERM;
+        double w = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
+        W[idx] = w;
+    }
+    for (int q = tid; q < lv.lds_g0; q += NT) smem[WSZ + q] = 0.0;
+    for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
+    const double *xc = x + cell * lv.ld;
+    for (int t = tid; t < nf; t += NT) xs[(uint32_t)lv.meta[t] & 0xffffu] = xc[t];
+    __syncthreads();
+
+    const uint32_t dm = use_mask ? dmask[cell] : 0u;
+    const double *sc = src ? src + cell * lv.ld : nullptr;
+    double *oc = out + cell * lv.ld;
+    for (int t = tid; t < nf; t += NT) {
+        const uint64_t mt = lv.meta[t];
+        const int L = (int)(mt & 0xffffu), len = (int)((mt >> 16) & 0xffu), cls = (int)((mt >> 24) & 0xffu);
+        const int A = (int)((mt >> 32) & 0xffffu), B = (int)(mt >> 48);
+        double acc = stencil_eval<DIM>(W + cls * NDIR, xs + L, len, A, B);
+        double o = sc ? sc[t] + acc : acc;
+        if (cls > 0 && ((dm >> (cls - 1)) & 1u)) o = 0.0;
+        oc[t] = o;
+    }
+}
+
+// Persistent variant: a workgroup walks over many cells; the per-slot addressing words live in
+// registers for the whole kernel, the next cell's column is prefetched into registers while the
+// current one is being evaluated, interior-class weights stay in registers.
+template <int DIM, int NT, int SPT>
+__global__ void __launch_bounds__(NT)
+k_apply_persist(LevelDev lv, int64_t ncells, const double *__restrict__ coef, const uint16_t *__restrict__ dmask,
+                double alpha, double lambda, const double *__restrict__ x, const double *src, double *out,
+                int use_mask)
+{
+    constexpr int NDIR = DIM == 3 ? 15 : 7;
+    constexpr int NTERM = DIM == 3 ? 7 : 4;
+    extern __shared__ double smem[];
+    double *W = smem;
+    double *xs = smem + WSZ + lv.lds_g0;
+    const int tid = threadIdx.x;
+    const int nf = lv.nf;
+
+    uint64_t mt[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int t = tid + q * NT;
+        mt[q] = t < nf ? lv.meta[t] : 0ull;
+    }
+    for (int q = tid; q < lv.lds_g0; q += NT) smem[WSZ + q] = 0.0;
+    for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
+
+    int64_t cell = blockIdx.x;
+    double xr[SPT];
+    if (cell < ncells) {
+        const double *xc = x + cell * lv.ld;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int t = tid + q * NT;
+            xr[q] = t < nf ? xc[t] : 0.0;
+        }
+    }
+    for (; cell < ncells; cell += gridDim.x) {
+        double s[NTERM];
+        cell_scales<DIM>(coef + cell * 8, alpha, lambda, s);
+        for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
+            const double *c = lv.ctab + (size_t)idx * NTERM;
+            double w = 0.0;
+#pragma unroll
+            for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
+            W[idx] = w;
+        }
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int t = tid + q * NT;
+            if (t < nf) xs[(uint32_t)mt[q] & 0xffffu] = xr[q];
+        }
+        __syncthreads();
+
+        // prefetch the next cell's column
+        const int64_t next = cell + gridDim.x;
+        if (next < ncells) {
+            const double *xn = x + next * lv.ld;
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                xr[q] = t < nf ? xn[t] : 0.0;
+            }
+        }
+        double w0[NDIR];
+#pragma unroll
+        for (int d = 0; d < NDIR; ++d) {
+            const double *c = lv.ctab + (size_t)d * NTERM;   // class 0 = cell interior
+            double w = 0.0;
+#pragma unroll
+            for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
+            w0[d] = w;
+        }
+        const uint32_t dm = use_mask ? dmask[cell] : 0u;
+        const double *sc = src ? src + cell * lv.ld : nullptr;
+        double *oc = out + cell * lv.ld;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int t = tid + q * NT;
+            if (t < nf) {
+                const uint64_t m = mt[q];
+                const int L = (int)(m & 0xffffu), len = (int)((m >> 16) & 0xffu), cls = (int)((m >> 24) & 0xffu);
+                const int A = (int)((m >> 32) & 0xffffu), B = (int)(m >> 48);
+                double acc;
+                if (cls == 0)
+                    acc = stencil_eval<DIM>(w0, xs + L, len, A, B);
+                else
+                    acc = stencil_eval<DIM>(W + cls * NDIR, xs + L, len, A, B);
+                double o = sc ? sc[t] + acc : acc;
+                if (cls > 0 && ((dm >> (cls - 1)) & 1u)) o = 0.0;
+                oc[t] = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t apply_lds_bytes(const LevelDev &lv)
+{
+    return sizeof(double) * (size_t)(WSZ + lv.lds_g0 + lv.nf + lv.lds_g1);
+}
+
+template <int DIM, int NT>
+static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
+                                 const double *x, const double *src, double *out, int use_mask, size_t lds)
+{
+    auto kern = k_apply<DIM, NT>;
+    if (lds > 48 * 1024)
+        HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, alpha,
+                       lambda, x, src, out, use_mask);
+    check_launch();
+}
+
+template <int DIM, int NT, int SPT>
+static void launch_apply_persist(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
+                                 const double *x, const double *src, double *out, int use_mask, size_t lds)
+{
+    auto kern = k_apply_persist<DIM, NT, SPT>;
+    if (lds > 48 * 1024)
+        HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = (int)((160 * 1024) / lds);
+    int by_waves = 2048 / NT;
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = (int64_t)L.num_cu * per_cu;
+    if (grid > mesh.ncells) grid = mesh.ncells;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, L.stream, lv, mesh.ncells, mesh.coef, mesh.dmask,
+                       alpha, lambda, x, src, out, use_mask);
+    check_launch();
+}
+
+template <int DIM>
+static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
+                             const double *x, const double *src, double *out, int use_mask)
+{
+    const size_t lds = apply_lds_bytes(lv);
+    if (lds > 160 * 1024)
+        throw std::runtime_error("operator apply: a cell of level " + std::to_string(lv.level) +
+                                 " does not fit the 160 KiB LDS (sub-blocked variant not built yet)");
+    const int nf = lv.nf;
+    if (L.apply_variant == 1 && nf > 256) {
+        int nt = L.apply_threads ? L.apply_threads : (nf > 2048 ? 512 : 256);
+        int spt = (nf + nt - 1) / nt;
+#define HMG_P(NT_, SPT_)                                                                             \
+    if (nt == NT_ && spt <= SPT_) {                                                                  \
+        launch_apply_persist<DIM, NT_, SPT_>(L, lv, mesh, alpha, lambda, x, src, out, use_mask, lds); \
+        return;                                                                                      \
+    }
+        HMG_P(256, 4)
+        HMG_P(256, 8)
+        HMG_P(256, 16)
+        HMG_P(256, 26)
+        HMG_P(512, 2)
+        HMG_P(512, 4)
+        HMG_P(512, 8)
+        HMG_P(512, 13)
+        HMG_P(512, 17)
+        HMG_P(1024, 7)
+        HMG_P(1024, 9)
+#undef HMG_P
+    }
+    if (nf <= 64)
+        launch_apply_generic<DIM, 64>(L, lv, mesh, alpha, lambda, x, src, out, use_mask, lds);
+    else if (nf <= 1024 || L.apply_threads == 256)
+        launch_apply_generic<DIM, 256>(L, lv, mesh, alpha, lambda, x, src, out, use_mask, lds);
+    else
+        launch_apply_generic<DIM, 512>(L, lv, mesh, alpha, lambda, x, src, out, use_mask, lds);
+}
+
+void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
+                  const double *x, const double *src, double *out, int use_mask)
+{
+    if (lv.dim == 3)
+        launch_apply_dim<3>(L, lv, mesh, alpha, lambda, x, src, out, use_mask);
+    else
+        launch_apply_dim<2>(L, lv, mesh, alpha, lambda, x, src, out, use_mask);
+}
+
+// ---------------------------------------------------------------------------------------------
+// interface sum: every shared entity is one contiguous, identically ordered run in each copy
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_iface_faces(const int32_t *__restrict__ pairs, int64_t npairs, int nfi, int off_face, int ld, double *x)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; p < npairs; p += nw) {
+        const int32_t ca = pairs[3 * p], cb = pairs[3 * p + 1], lf = pairs[3 * p + 2];
+        double *a = x + (int64_t)ca * ld + off_face + (lf & 15) * nfi;
+        double *b = x + (int64_t)cb * ld + off_face + (lf >> 4) * nfi;
+        for (int k = lane; k < nfi; k += 64) {
+            const double s = a[k] + b[k];   // (0 + a) + b, ascending cell order
+            a[k] = s;
+            b[k] = s;
+        }
+    }
+}
+
+// CSR entities (edges: per = nei at offset off_edge + lid*nei; nodes: per = 1 at offset lid)
+__global__ void __launch_bounds__(256)
+k_iface_csr(const int32_t *__restrict__ ptr, const int32_t *__restrict__ ent, int64_t nent, int per, int off, int ld,
+            double *x)
+{
+    const int64_t total = nent * per;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = idx / per;
+        const int k = (int)(idx - e * per);
+        const int b = ptr[e], end = ptr[e + 1];
+        double s = 0.0;
+        for (int q = b; q < end; ++q) {
+            const int32_t v = ent[q];
+            s += x[(int64_t)(v >> 3) * ld + off + (v & 7) * per + k];
+        }
+        for (int q = b; q < end; ++q) {
+            const int32_t v = ent[q];
+            x[(int64_t)(v >> 3) * ld + off + (v & 7) * per + k] = s;
+        }
+    }
+}
+
+void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x)
+{
+    const int cap = L.num_cu * 8;
+    if (lv.dim == 3 && lv.nfi > 0 && mesh.nfacepairs > 0) {
+        int64_t blocks = (mesh.nfacepairs + 3) / 4;
+        if (lv.nfi < 64) blocks = (mesh.nfacepairs + 3) / 4;
+        if (blocks > cap * 4) blocks = cap * 4;
+        hipLaunchKernelGGL(k_iface_faces, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.face_pairs,
+                           mesh.nfacepairs, lv.nfi, lv.off_face, lv.ld, x);
+        check_launch();
+    }
+    if (lv.nei > 0 && mesh.nsharededges > 0) {
+        int64_t total = mesh.nsharededges * lv.nei;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > cap * 4) blocks = cap * 4;
+        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.edge_ptr, mesh.edge_ent,
+                           mesh.nsharededges, lv.nei, lv.off_edge, lv.ld, x);
+        check_launch();
+    }
+    if (mesh.nsharednodes > 0) {
+        int64_t blocks = (mesh.nsharednodes + 255) / 256;
+        if (blocks > cap * 4) blocks = cap * 4;
+        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.node_ptr, mesh.node_ent,
+                           mesh.nsharednodes, 1, 0, lv.ld, x);
+        check_launch();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// entity masks (Dirichlet constraint / duplicate zeroing)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void entity_range(const LevelDev &lv, int bit, int &off, int &len)
+{
+    if (bit < lv.nface) {
+        off = lv.off_face + bit * lv.nfi;
+        len = lv.nfi;
+    } else if (bit < lv.nface + lv.nedge) {
+        off = lv.off_edge + (bit - lv.nface) * lv.nei;
+        len = lv.nei;
+    } else {
+        off = bit - lv.nface - lv.nedge;
+        len = 1;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_mask(LevelDev lv, int64_t ncells, const uint16_t *__restrict__ mask, double *x)
+{
+    const int64_t cell = blockIdx.x;
+    if (cell >= ncells) return;
+    uint32_t m = mask[cell];
+    double *xc = x + cell * lv.ld;
+    while (m) {
+        const int bit = __ffs((int)m) - 1;
+        m &= m - 1;
+        int off, len;
+        entity_range(lv, bit, off, len);
+        for (int k = threadIdx.x; k < len; k += 64) xc[off + k] = 0.0;
+    }
+}
+
+void launch_mask(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which)
+{
+    hipLaunchKernelGGL(k_mask, dim3((unsigned)mesh.ncells), dim3(64), 0, L.stream, lv, mesh.ncells,
+                       which == 0 ? mesh.dmask : mesh.dupmask, x);
+    check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// level transfer
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_prolong_add(LevelDev fine, int nfc, int ldc, const double *__restrict__ xc, double *xf)
+{
+    extern __shared__ double smem[];
+    const int64_t cell = blockIdx.x;
+    const double *c = xc + cell * ldc;
+    for (int t = threadIdx.x; t < nfc; t += NT) smem[t] = c[t];
+    __syncthreads();
+    double *f = xf + cell * fine.ld;
+    for (int t = threadIdx.x; t < fine.nf; t += NT) {
+        const int a = fine.par_a[t], b = fine.par_b[t];
+        double y = f[t];
+        if (a == b)
+            y += 1.0 * smem[a];
+        else {
+            y += 0.5 * smem[a];   // CSC column order: parent with the smaller hierarchical id first
+            y += 0.5 * smem[b];
+        }
+        f[t] = y;
+    }
+}
+
+template <int NT, bool USE_LDS>
+__global__ void __launch_bounds__(NT)
+k_restrict(LevelDev fine, int nfc, int ldc, const double *__restrict__ rf, double *bc)
+{
+    extern __shared__ double smem[];
+    const int64_t cell = blockIdx.x;
+    const double *f = rf + cell * fine.ld;
+    const double *fs = f;
+    if (USE_LDS) {
+        for (int t = threadIdx.x; t < fine.nf; t += NT) smem[t] = f[t];
+        __syncthreads();
+        fs = smem;
+    }
+    double *c = bc + cell * ldc;
+    for (int t = threadIdx.x; t < nfc; t += NT) {
+        const int b = fine.rptr[t], e = fine.rptr[t + 1];
+        double tmp = 0.0;
+        tmp += 1.0 * fs[fine.ridx[b]];
+        for (int q = b + 1; q < e; ++q) tmp += 0.5 * fs[fine.ridx[q]];
+        c[t] = tmp;
+    }
+}
+
+void launch_prolong_add(const Launch &L, const LevelDev &fine, const LevelDev &coarse, int64_t ncells,
+                        const double *xc, double *xf)
+{
+    size_t lds = sizeof(double) * coarse.nf;
+    if (lds > 160 * 1024) throw std::runtime_error("prolongation: coarse cell does not fit LDS");
+    if (fine.nf <= 256) {
+        auto k = k_prolong_add<64>;
+        hipLaunchKernelGGL(k, dim3((unsigned)ncells), dim3(64), lds, L.stream, fine, coarse.nf, coarse.ld, xc, xf);
+    } else {
+        auto k = k_prolong_add<256>;
+        if (lds > 48 * 1024)
+            HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)ncells), dim3(256), lds, L.stream, fine, coarse.nf, coarse.ld, xc, xf);
+    }
+    check_launch();
+}
+
+void launch_restrict(const Launch &L, const LevelDev &fine, const LevelDev &coarse, int64_t ncells,
+                     const double *rf, double *bc)
+{
+    size_t lds = sizeof(double) * fine.nf;
+    if (fine.nf <= 256) {
+        hipLaunchKernelGGL((k_restrict<64, true>), dim3((unsigned)ncells), dim3(64), lds, L.stream, fine, coarse.nf,
+                           coarse.ld, rf, bc);
+    } else if (lds <= 160 * 1024) {
+        auto k = k_restrict<256, true>;
+        if (lds > 48 * 1024)
+            HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)ncells), dim3(256), lds, L.stream, fine, coarse.nf, coarse.ld, rf, bc);
+    } else {
+        hipLaunchKernelGGL((k_restrict<256, false>), dim3((unsigned)ncells), dim3(256), 0, L.stream, fine, coarse.nf,
+                           coarse.ld, rf, bc);
+    }
+    check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming vector kernels (flat storage, every copy of a shared DOF counted -- BLAS semantics)
+// ---------------------------------------------------------------------------------------------
+static inline int stream_blocks(const Launch &L, int64_t n, int per_thread)
+{
+    int64_t b = (n + (int64_t)256 * per_thread - 1) / ((int64_t)256 * per_thread);
+    int64_t cap = (int64_t)L.num_cu * 8;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ void __launch_bounds__(256) k_fill(double *x, int64_t n, double v)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) x2[i] = make_double2(v, v);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = v;
+}
+
+__global__ void __launch_bounds__(256) k_copy(double *dst, const double *__restrict__ src, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) d2[i] = s2[i];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+
+__global__ void __launch_bounds__(256) k_axpy(double a, const double *__restrict__ x, double *y, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *y2 = reinterpret_cast<double2 *>(y);
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 xv = x2[i], yv = y2[i];
+        yv.x += a * xv.x;
+        yv.y += a * xv.y;
+        y2[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] += a * x[n - 1];
+}
+
+__global__ void __launch_bounds__(256) k_xpby(const double *__restrict__ r, double b, double *p, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 rv = r2[i], pv = p2[i];
+        pv.x = rv.x + b * pv.x;
+        pv.y = rv.y + b * pv.y;
+        p2[i] = pv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + b * p[n - 1];
+}
+
+__global__ void __launch_bounds__(256)
+k_dot(const double *__restrict__ x, const double *__restrict__ y, int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    const double2 *y2 = reinterpret_cast<const double2 *>(y);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 xv = x2[i], yv = y2[i];
+        acc += xv.x * yv.x;
+        acc += xv.y * yv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * y[n - 1];
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_copy_dot(double *p, const double *__restrict__ r, int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 rv = r2[i];
+        p2[i] = rv;
+        acc += rv.x * rv.x;
+        acc += rv.y * rv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        p[n - 1] = r[n - 1];
+        acc += r[n - 1] * r[n - 1];
+    }
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_cg_update(double *x, double *r, const double *__restrict__ p, const double *__restrict__ q, int64_t n,
+            const double *__restrict__ scal, int s_num, int s_den, double *partials)
+{
+    __shared__ double red[4];
+    const double alpha = scal[s_num] / scal[s_den];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *p2 = reinterpret_cast<const double2 *>(p);
+    const double2 *q2 = reinterpret_cast<const double2 *>(q);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 xv = x2[i], rv = r2[i], pv = p2[i], qv = q2[i];
+        xv.x += alpha * pv.x;
+        xv.y += alpha * pv.y;
+        rv.x += (-alpha) * qv.x;
+        rv.y += (-alpha) * qv.y;
+        x2[i] = xv;
+        r2[i] = rv;
+        acc += rv.x * rv.x;
+        acc += rv.y * rv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] += alpha * p[n - 1];
+        double rv = r[n - 1] + (-alpha) * q[n - 1];
+        r[n - 1] = rv;
+        acc += rv * rv;
+    }
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_cg_pupdate(double *p, const double *__restrict__ r, int64_t n, const double *__restrict__ scal, int s_num, int s_den)
+{
+    const double beta = scal[s_num] / scal[s_den];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 rv = r2[i], pv = p2[i];
+        pv.x = rv.x + beta * pv.x;
+        pv.y = rv.y + beta * pv.y;
+        p2[i] = pv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + beta * p[n - 1];
+}
+
+static void finalize(const Launch &L, int nb, int slot)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, nb, L.scal, slot);
+    check_launch();
+}
+
+void launch_fill(const Launch &L, double *x, int64_t n, double v)
+{
+    hipLaunchKernelGGL(k_fill, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, x, n, v);
+    check_launch();
+}
+void launch_copy(const Launch &L, double *dst, const double *src, int64_t n)
+{
+    hipLaunchKernelGGL(k_copy, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, dst, src, n);
+    check_launch();
+}
+void launch_axpy(const Launch &L, double a, const double *x, double *y, int64_t n)
+{
+    hipLaunchKernelGGL(k_axpy, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, a, x, y, n);
+    check_launch();
+}
+void launch_xpby(const Launch &L, const double *r, double b, double *p, int64_t n)
+{
+    hipLaunchKernelGGL(k_xpby, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, r, b, p, n);
+    check_launch();
+}
+void launch_dot(const Launch &L, const double *x, const double *y, int64_t n, int slot)
+{
+    int nb = stream_blocks(L, n, 8);
+    hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, L.stream, x, y, n, L.partials);
+    check_launch();
+    finalize(L, nb, slot);
+}
+void launch_copy_dot(const Launch &L, double *p, const double *r, int64_t n, int slot)
+{
+    int nb = stream_blocks(L, n, 8);
+    hipLaunchKernelGGL(k_copy_dot, dim3(nb), dim3(256), 0, L.stream, p, r, n, L.partials);
+    check_launch();
+    finalize(L, nb, slot);
+}
+void launch_cg_update(const Launch &L, double *x, double *r, const double *p, const double *q, int64_t n, int s_num,
+                      int s_den, int s_out)
+{
+    int nb = stream_blocks(L, n, 8);
+    hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, L.stream, x, r, p, q, n, L.scal, s_num, s_den, L.partials);
+    check_launch();
+    finalize(L, nb, s_out);
+}
+void launch_cg_pupdate(const Launch &L, double *p, const double *r, int64_t n, int s_num, int s_den)
+{
+    hipLaunchKernelGGL(k_cg_pupdate, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, p, r, n, L.scal, s_num,
+                       s_den);
+    check_launch();
+}
+
+// sum over first copies only: cell-wise, entities flagged in dupmask skipped
+__global__ void __launch_bounds__(256)
+k_norm2_unique(LevelDev lv, int64_t ncells, const uint16_t *__restrict__ dupmask, const double *__restrict__ x,
+               double *partials)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t cell = blockIdx.x; cell < ncells; cell += gridDim.x) {
+        const uint32_t dm = dupmask[cell];
+        const double *xc = x + cell * lv.ld;
+        for (int t = threadIdx.x; t < lv.nf; t += 256) {
+            const int cls = (int)((lv.meta[t] >> 24) & 0xffu);
+            const bool dup = cls > 0 && ((dm >> (cls - 1)) & 1u);
+            const double v = xc[t];
+            if (!dup) acc += v * v;
+        }
+    }
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+void launch_norm2_unique(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *x, int slot)
+{
+    int64_t nb = mesh.ncells;
+    if (nb > (int64_t)L.num_cu * 8) nb = (int64_t)L.num_cu * 8;
+    hipLaunchKernelGGL(k_norm2_unique, dim3((unsigned)nb), dim3(256), 0, L.stream, lv, mesh.ncells, mesh.dupmask, x,
+                       L.partials);
+    check_launch();
+    finalize(L, (int)nb, slot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// level-1 gather / scatter (level-1 storage slot == local node id)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_gather_base(const int32_t *__restrict__ node_first, int64_t nnodes, int ld1, const double *__restrict__ v1, double *u)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nnodes) return;
+    const int32_t v = node_first[g];
+    u[g] = v >= 0 ? v1[(int64_t)(v >> 3) * ld1 + (v & 7)] : 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+k_scatter_base(const int32_t *__restrict__ cells, int64_t ncells, int npc, int ld1, const double *__restrict__ u,
+               double *v1)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncells * npc) return;
+    const int64_t c = i / npc;
+    const int l = (int)(i - c * npc);
+    v1[c * ld1 + l] = u[cells[i]];
+}
+
+void launch_gather_base(const Launch &L, const MeshDev &mesh, int ld1, const double *v1, double *u)
+{
+    hipLaunchKernelGGL(k_gather_base, dim3((unsigned)((mesh.nnodes + 255) / 256)), dim3(256), 0, L.stream,
+                       mesh.node_first, mesh.nnodes, ld1, v1, u);
+    check_launch();
+}
+void launch_scatter_base(const Launch &L, const MeshDev &mesh, int ld1, const double *u, double *v1)
+{
+    const int npc = mesh.dim + 1;
+    hipLaunchKernelGGL(k_scatter_base, dim3((unsigned)((mesh.ncells * npc + 255) / 256)), dim3(256), 0, L.stream,
+                       mesh.cells, mesh.ncells, npc, ld1, u, v1);
+    check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// API order (hierarchical, Nf x Ne column-major) <-> storage order; deterministic synthetic fill
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_permute(LevelDev lv, int64_t ncells, const double *__restrict__ src, double *dst, int to_storage)
+{
+    const int64_t total = ncells * lv.nf;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i / lv.nf;
+        const int h = (int)(i - c * lv.nf);
+        const int s = lv.hier2slot[h];
+        if (to_storage)
+            dst[c * lv.ld + s] = src[i];
+        else
+            dst[i] = src[c * lv.ld + s];
+    }
+}
+
+void launch_permute(const Launch &L, const LevelDev &lv, int64_t ncells, const double *src, double *dst, int to_storage)
+{
+    hipLaunchKernelGGL(k_permute, dim3(stream_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, src,
+                       dst, to_storage);
+    check_launch();
+}
+
+__device__ __forceinline__ double hash_u01(uint64_t seed, uint64_t idx)
+{
+    uint64_t z = seed + (idx + 1ull) * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// x[hier h, cell c] = u01(seed, ((c + cell_offset) << 20) | h): independent of the storage order
+__global__ void __launch_bounds__(256)
+k_fill_random(LevelDev lv, int64_t ncells, double *x, uint64_t seed, int64_t cell_offset)
+{
+    const int64_t total = ncells * lv.nf;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i / lv.nf;
+        const int h = (int)(i - c * lv.nf);
+        x[c * lv.ld + lv.hier2slot[h]] = hash_u01(seed, ((uint64_t)(c + cell_offset) << 20) | (uint64_t)h);
+    }
+}
+
+void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, double *x, uint64_t seed,
+                        int64_t cell_offset)
+{
+    hipLaunchKernelGGL(k_fill_random, dim3(stream_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, x,
+                       seed, cell_offset);
+    check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// coarse (level-1) Jacobi-PCG on the assembled interior matrix
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_coarse_gather_rhs(const int32_t *__restrict__ interior, int64_t n, const double *__restrict__ u, double *b)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = u[interior[i]];
+}
+
+__global__ void __launch_bounds__(256)
+k_coarse_scatter_sol(const int32_t *__restrict__ interior, int64_t n, const double *__restrict__ x, double *u)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) u[interior[i]] = x[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_coarse_init(CoarseDev A, const double *__restrict__ b, double *x, double *r, double *z, double *p, double *part0,
+              double *part1)
+{
+    __shared__ double red[4];
+    double rz = 0.0, bb = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double bi = b[i];
+        const double zi = bi / A.diag[i];
+        x[i] = 0.0;
+        r[i] = bi;
+        z[i] = zi;
+        p[i] = zi;
+        rz += bi * zi;
+        bb += bi * bi;
+    }
+    double s0 = block_sum(rz, red);
+    double s1 = block_sum(bb, red);
+    if (threadIdx.x == 0) {
+        part0[blockIdx.x] = s0;
+        part1[blockIdx.x] = s1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_coarse_spmv_dot(CoarseDev A, const double *__restrict__ p, double *q, double *partials)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) s += A.val[k] * p[A.colidx[k]];
+        q[i] = s;
+        acc += p[i] * s;
+    }
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__restrict__ p, const double *__restrict__ q,
+                const double *__restrict__ scal, double *part0, double *part1)
+{
+    __shared__ double red[4];
+    const double alpha = scal[S_C0] / scal[S_C1];
+    double rz = 0.0, rr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * q[i];
+        const double zi = ri / A.diag[i];
+        r[i] = ri;
+        z[i] = zi;
+        rz += ri * zi;
+        rr += ri * ri;
+    }
+    double s0 = block_sum(rz, red);
+    double s1 = block_sum(rr, red);
+    if (threadIdx.x == 0) {
+        part0[blockIdx.x] = s0;
+        part1[blockIdx.x] = s1;
+    }
+}
+
+// beta = C3/C0; p = z + beta p.  The last block to finish also rolls C0 <- C3 ... done on a
+// separate tiny launch instead (k_roll) to keep every read of C0 ahead of its overwrite.
+__global__ void __launch_bounds__(256)
+k_coarse_pupdate(CoarseDev A, double *p, const double *__restrict__ z, const double *__restrict__ scal)
+{
+    const double beta = scal[S_C3] / scal[S_C0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = z[i] + beta * p[i];
+}
+
+__global__ void k_roll(double *scal, int dst, int src) { scal[dst] = scal[src]; }
+
+static inline int coarse_blocks(const Launch &L, int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+void launch_coarse_gather_rhs(const Launch &L, const CoarseDev &A, const double *u, double *b)
+{
+    hipLaunchKernelGGL(k_coarse_gather_rhs, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, L.stream, A.interior,
+                       A.n, u, b);
+    check_launch();
+}
+void launch_coarse_scatter_sol(const Launch &L, const CoarseDev &A, int64_t nnodes, const double *x, double *u)
+{
+    launch_fill(L, u, nnodes, 0.0);
+    hipLaunchKernelGGL(k_coarse_scatter_sol, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, L.stream, A.interior,
+                       A.n, x, u);
+    check_launch();
+}
+void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z, double *p)
+{
+    int nb = coarse_blocks(L, A.n);
+    hipLaunchKernelGGL(k_coarse_init, dim3(nb), dim3(256), 0, L.stream, A, b, x, r, z, p, L.partials, L.partials + 2048);
+    check_launch();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, nb, L.scal, (int)S_C0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, nb, L.scal, (int)S_C2);
+    check_launch();
+}
+void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q)
+{
+    int nb = coarse_blocks(L, A.n);
+    hipLaunchKernelGGL(k_coarse_spmv_dot, dim3(nb), dim3(256), 0, L.stream, A, p, q, L.partials);
+    check_launch();
+    finalize(L, nb, S_C1);
+}
+void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
+                          const double *q)
+{
+    int nb = coarse_blocks(L, A.n);
+    hipLaunchKernelGGL(k_coarse_update, dim3(nb), dim3(256), 0, L.stream, A, x, r, z, p, q, L.scal, L.partials,
+                       L.partials + 2048);
+    check_launch();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, nb, L.scal, (int)S_C3);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, nb, L.scal, (int)S_TMP);
+    check_launch();
+}
+void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z)
+{
+    hipLaunchKernelGGL(k_coarse_pupdate, dim3(coarse_blocks(L, A.n)), dim3(256), 0, L.stream, A, p, z, L.scal);
+    check_launch();
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, L.stream, L.scal, (int)S_C0, (int)S_C3);
+    check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU: pack one value per cut DOF (first local copy) / write the summed value to all copies
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_cut_pack(LevelDev lv, int kind, int64_t nentries, const int64_t *__restrict__ gid,
+           const int32_t *__restrict__ cell_lid, const uint8_t *__restrict__ first, double *buf, double *x, int unpack)
+{
+    const int per = kind == 0 ? lv.nfi : kind == 1 ? lv.nei : 1;
+    const int off = kind == 0 ? lv.off_face : kind == 1 ? lv.off_edge : 0;
+    const int64_t total = nentries * per;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = idx / per;
+        const int k = (int)(idx - e * per);
+        const int32_t v = cell_lid[e];
+        double *a = x + (int64_t)(v >> 3) * lv.ld + off + (v & 7) * per + k;
+        double *b = buf + gid[e] * per + k;
+        if (unpack)
+            *a = *b;
+        else if (first[e])
+            *b = *a;
+    }
+}
+
+void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nentries, const int64_t *gid,
+                     const int32_t *cell_lid, const uint8_t *first, double *buf, double *x, int unpack)
+{
+    const int per = kind == 0 ? lv.nfi : kind == 1 ? lv.nei : 1;
+    hipLaunchKernelGGL(k_cut_pack, dim3(stream_blocks(L, nentries * per, 1)), dim3(256), 0, L.stream, lv, kind,
+                       nentries, gid, cell_lid, first, buf, x, unpack);
+    check_launch();
+}
+
+}  // namespace hmg

@@ -1,0 +1,339 @@
+// Base-mesh tables: shared-entity lists for the interface sum, Dirichlet / duplicate masks,
+// cell geometry and operator coefficients, coarse-level matrix.
+//
+// Behavioural contract (what the lists contain and in which order copies are summed) follows
+// src/interface.jl:65-117,124-197,207-284 and src/implicit_fine_grid.jl:94-139,209-386 of the
+// reference; the data structures are this library's own: faces as explicit pairs, per-cell entity
+// bitmasks instead of (element, local id) value lists.
+#include "hmg_host.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <stdexcept>
+#include <unordered_set>
+
+namespace hmg {
+
+namespace {
+
+struct Ent {
+    std::array<int32_t, 3> key;
+    int32_t cell;
+    int32_t lid;
+};
+
+inline bool ent_less(const Ent &a, const Ent &b)
+{
+    if (a.key != b.key) return a.key < b.key;
+    return a.cell < b.cell;   // element-major listing + stable sort in the reference
+}
+
+const int TET_FACES[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};
+const int TET_EDGES[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+const int TRI_EDGES[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+
+std::vector<Ent> list_entities(const MeshTables &M, int kind /*0 node,1 edge,2 face*/)
+{
+    const int N = M.dim + 1;
+    const int per = kind == 0 ? N : kind == 1 ? (M.dim == 3 ? 6 : 3) : 4;
+    std::vector<Ent> v;
+    v.reserve((size_t)M.ncells * per);
+    for (int64_t c = 0; c < M.ncells; ++c) {
+        const int32_t *el = &M.cells[c * N];
+        for (int l = 0; l < per; ++l) {
+            Ent e;
+            e.cell = (int32_t)c;
+            e.lid = l;
+            if (kind == 0)
+                e.key = {el[l], -1, -1};
+            else if (kind == 1) {
+                const int *t = M.dim == 3 ? TET_EDGES[l] : TRI_EDGES[l];
+                e.key = {el[t[0]], el[t[1]], -1};
+            } else
+                e.key = {el[TET_FACES[l][0]], el[TET_FACES[l][1]], el[TET_FACES[l][2]]};
+            v.push_back(e);
+        }
+    }
+    std::sort(v.begin(), v.end(), ent_less);
+    return v;
+}
+
+template <class F>
+void for_groups(const std::vector<Ent> &v, F f)
+{
+    size_t i = 0;
+    while (i < v.size()) {
+        size_t j = i + 1;
+        while (j < v.size() && v[j].key == v[i].key) ++j;
+        f(i, j);
+        i = j;
+    }
+}
+
+struct Geo {
+    double J[3][3], Jinv[3][3], det;   // Jinv = inv(J')
+};
+
+Geo cell_geo(const MeshTables &M, int64_t c)
+{
+    const int dim = M.dim, N = dim + 1;
+    const int32_t *el = &M.cells[c * N];
+    Geo g{};
+    const double *p0 = &M.coords[(size_t)el[0] * dim];
+    for (int col = 0; col < dim; ++col) {
+        const double *p = &M.coords[(size_t)el[col + 1] * dim];
+        for (int a = 0; a < dim; ++a) g.J[a][col] = p[a] - p0[a];
+    }
+    double inv[3][3] = {{0}};
+    if (dim == 2) {
+        double det = g.J[0][0] * g.J[1][1] - g.J[0][1] * g.J[1][0];
+        inv[0][0] = g.J[1][1] / det;
+        inv[0][1] = -g.J[0][1] / det;
+        inv[1][0] = -g.J[1][0] / det;
+        inv[1][1] = g.J[0][0] / det;
+        g.det = std::fabs(det);
+    } else {
+        const double(*J)[3] = g.J;
+        double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        inv[0][0] = c00 / det;
+        inv[1][0] = c01 / det;
+        inv[2][0] = c02 / det;
+        inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+        inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+        inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+        inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+        inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+        inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+        g.det = std::fabs(det);
+    }
+    for (int a = 0; a < dim; ++a)
+        for (int b = 0; b < dim; ++b) g.Jinv[a][b] = inv[b][a];   // inv(J') = inv(J)'
+    return g;
+}
+
+void build_from_cells0(MeshTables &M)
+{
+    const int dim = M.dim, N = dim + 1;
+    const int nface = dim == 3 ? 4 : 0, nedge = dim == 3 ? 6 : 3;
+    auto bit_face = [&](int f) { return (uint16_t)(1u << f); };
+    auto bit_edge = [&](int e) { return (uint16_t)(1u << (nface + e)); };
+    auto bit_node = [&](int n) { return (uint16_t)(1u << (nface + nedge + n)); };
+
+    for (int64_t c = 0; c < M.ncells; ++c)
+        for (int l = 0; l + 1 < N; ++l)
+            if (!(M.cells[c * N + l] < M.cells[c * N + l + 1]))
+                throw std::runtime_error("base mesh: every cell's node tuple must be strictly ascending");
+
+    M.dmask.assign(M.ncells, 0);
+    M.dupmask.assign(M.ncells, 0);
+    M.node_on_boundary.assign(M.nnodes, 0);
+    M.face_pairs.clear();
+    M.edge_ptr.assign(1, 0);
+    M.edge_ent.clear();
+    M.node_ptr.assign(1, 0);
+    M.node_ent.clear();
+    M.node_first.assign(M.nnodes, -1);
+
+    std::unordered_set<uint64_t> bedges;
+    auto ekey = [&](int32_t a, int32_t b) { return (uint64_t)a * (uint64_t)M.nnodes + (uint64_t)b; };
+
+    if (dim == 3) {
+        auto faces = list_entities(M, 2);
+        for_groups(faces, [&](size_t i, size_t j) {
+            if (j - i == 1) {   // boundary face (src/interface.jl:209-215)
+                M.dmask[faces[i].cell] |= bit_face(faces[i].lid);
+                const auto &k = faces[i].key;
+                bedges.insert(ekey(k[0], k[1]));
+                bedges.insert(ekey(k[0], k[2]));
+                bedges.insert(ekey(k[1], k[2]));
+            } else if (j - i == 2) {
+                M.face_pairs.push_back(faces[i].cell);
+                M.face_pairs.push_back(faces[i + 1].cell);
+                M.face_pairs.push_back(faces[i].lid | (faces[i + 1].lid << 4));
+                M.dupmask[faces[i + 1].cell] |= bit_face(faces[i + 1].lid);
+            } else
+                throw std::runtime_error("base mesh: a face is shared by more than two cells");
+        });
+    }
+    {
+        auto edges = list_entities(M, 1);
+        if (dim == 2)
+            for_groups(edges, [&](size_t i, size_t j) {
+                if (j - i == 1) bedges.insert(ekey(edges[i].key[0], edges[i].key[1]));
+                if (j - i > 2) throw std::runtime_error("base mesh: an edge is shared by more than two triangles");
+            });
+        for_groups(edges, [&](size_t i, size_t j) {
+            bool bnd = bedges.count(ekey(edges[i].key[0], edges[i].key[1])) != 0;
+            if (bnd) {
+                M.node_on_boundary[edges[i].key[0]] = 1;
+                M.node_on_boundary[edges[i].key[1]] = 1;
+            }
+            for (size_t q = i; q < j; ++q) {
+                if (bnd) M.dmask[edges[q].cell] |= bit_edge(edges[q].lid);
+                if (q > i) M.dupmask[edges[q].cell] |= bit_edge(edges[q].lid);
+            }
+            if (j - i >= 2) {   // singletons removed (src/interface.jl:99)
+                for (size_t q = i; q < j; ++q) M.edge_ent.push_back(edges[q].cell * 8 + edges[q].lid);
+                M.edge_ptr.push_back((int32_t)M.edge_ent.size());
+            }
+        });
+    }
+    {
+        auto nodes = list_entities(M, 0);
+        for_groups(nodes, [&](size_t i, size_t j) {
+            int32_t g = nodes[i].key[0];
+            M.node_first[g] = nodes[i].cell * 8 + nodes[i].lid;
+            bool bnd = M.node_on_boundary[g] != 0;
+            for (size_t q = i; q < j; ++q) {
+                if (bnd) M.dmask[nodes[q].cell] |= bit_node(nodes[q].lid);
+                if (q > i) M.dupmask[nodes[q].cell] |= bit_node(nodes[q].lid);
+            }
+            if (j - i >= 2) {
+                for (size_t q = i; q < j; ++q) M.node_ent.push_back(nodes[q].cell * 8 + nodes[q].lid);
+                M.node_ptr.push_back((int32_t)M.node_ent.size());
+            }
+        });
+    }
+
+    M.detj.resize(M.ncells);
+    M.jinv.resize((size_t)M.ncells * dim * dim);
+    for (int64_t c = 0; c < M.ncells; ++c) {
+        Geo g = cell_geo(M, c);
+        if (!(g.det > 0.0)) throw std::runtime_error("base mesh: degenerate cell");
+        M.detj[c] = g.det;
+        for (int b = 0; b < dim; ++b)
+            for (int a = 0; a < dim; ++a) M.jinv[(size_t)c * dim * dim + a + dim * b] = g.Jinv[a][b];
+    }
+}
+
+}  // namespace
+
+void build_mesh_tables(int dim, int64_t nnodes, const double *coords, int64_t ncells,
+                       const int64_t *cells_1based, MeshTables &M)
+{
+    if (dim != 2 && dim != 3) throw std::runtime_error("dim must be 2 or 3");
+    if (ncells <= 0 || nnodes <= 0) throw std::runtime_error("empty base mesh");
+    if (ncells >= (int64_t(1) << 27)) throw std::runtime_error("too many cells for one device partition");
+    const int N = dim + 1;
+    M.dim = dim;
+    M.nnodes = nnodes;
+    M.ncells = ncells;
+    M.coords.assign(coords, coords + (size_t)nnodes * dim);
+    M.cells.resize((size_t)ncells * N);
+    for (int64_t q = 0; q < ncells * N; ++q) {
+        int64_t v = cells_1based[q] - 1;
+        if (v < 0 || v >= nnodes) throw std::runtime_error("base mesh: node index out of range (cells are 1-based)");
+        M.cells[q] = (int32_t)v;
+    }
+    build_from_cells0(M);
+}
+
+void restrict_mesh_tables(const MeshTables &full, int64_t ncells_prefix, int64_t nnodes_prefix,
+                          MeshTables &M)
+{
+    if (ncells_prefix <= 0 || ncells_prefix > full.ncells || nnodes_prefix <= 0 || nnodes_prefix > full.nnodes)
+        throw std::runtime_error("shrink: prefix out of range");
+    const int N = full.dim + 1;
+    M.dim = full.dim;
+    M.nnodes = nnodes_prefix;
+    M.ncells = ncells_prefix;
+    M.coords.assign(full.coords.begin(), full.coords.begin() + (size_t)nnodes_prefix * full.dim);
+    M.cells.assign(full.cells.begin(), full.cells.begin() + (size_t)ncells_prefix * N);
+    for (int32_t v : M.cells)
+        if (v >= nnodes_prefix) throw std::runtime_error("shrink: a kept cell references a dropped node");
+    build_from_cells0(M);
+}
+
+void build_cell_coefficients(const MeshTables &M, const double *sigma, std::vector<double> &coef)
+{
+    const int dim = M.dim;
+    const int nterm = dim == 3 ? 7 : 4;
+    coef.assign((size_t)M.ncells * 8, 0.0);
+    for (int64_t c = 0; c < M.ncells; ++c) {
+        const double *Ji = &M.jinv[(size_t)c * dim * dim];   // column-major inv(J')
+        const double *sg = &sigma[(size_t)c * dim];
+        double det = M.detj[c];
+        int t = 0;
+        for (int a = 0; a < dim; ++a)
+            for (int b = a; b < dim; ++b, ++t) {
+                // P = Jinv' * (sigma .* Jinv)   (src/apply_local_operators.jl:105)
+                double s = 0.0;
+                for (int k = 0; k < dim; ++k) s += Ji[k + dim * a] * (sg[k] * Ji[k + dim * b]);
+                coef[(size_t)c * 8 + t] = det * s;
+            }
+        coef[(size_t)c * 8 + nterm - 1] = det;
+    }
+}
+
+void assemble_coarse_matrix(const MeshTables &M, const double *sigma, double lambda, CoarseMatrix &A)
+{
+    const int dim = M.dim, N = dim + 1;
+    A.node2int.assign(M.nnodes, -1);
+    A.interior.clear();
+    for (int64_t g = 0; g < M.nnodes; ++g)
+        if (!M.node_on_boundary[g] && M.node_first[g] >= 0) {
+            A.node2int[g] = (int32_t)A.interior.size();
+            A.interior.push_back((int32_t)g);
+        }
+    A.n = (int64_t)A.interior.size();
+    struct Trip {
+        int32_t r, c;
+        double v;
+    };
+    std::vector<Trip> trips;
+    trips.reserve((size_t)M.ncells * N * N);
+    const double volf = dim == 3 ? 1.0 / 6.0 : 0.5;
+    const double massf = dim == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
+    for (int64_t c = 0; c < M.ncells; ++c) {
+        const double *Ji = &M.jinv[(size_t)c * dim * dim];
+        const double *sg = &sigma[(size_t)c * dim];
+        const int32_t *el = &M.cells[c * N];
+        double vol = M.detj[c] * volf;
+        // gradients = Jinv * refgrads (src/cell_values.jl:117)
+        double g[3][4];
+        for (int a = 0; a < dim; ++a) {
+            double s = 0.0;
+            for (int k = 0; k < dim; ++k) {
+                g[a][k + 1] = Ji[a + dim * k];
+                s += Ji[a + dim * k];
+            }
+            g[a][0] = -s;
+        }
+        for (int i = 0; i < N; ++i) {
+            int32_t ri = A.node2int[el[i]];
+            if (ri < 0) continue;
+            for (int j = 0; j < N; ++j) {
+                int32_t cj = A.node2int[el[j]];
+                if (cj < 0) continue;
+                double k = 0.0;
+                for (int a = 0; a < dim; ++a) k += g[a][i] * sg[a] * g[a][j];
+                double v = vol * (k + lambda * massf * (i == j ? 2.0 : 1.0));
+                trips.push_back({ri, cj, v});
+            }
+        }
+    }
+    std::sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b) {
+        return a.r != b.r ? a.r < b.r : a.c < b.c;
+    });
+    A.rowptr.assign(A.n + 1, 0);
+    A.colidx.clear();
+    A.val.clear();
+    A.diag.assign(A.n, 0.0);
+    for (size_t q = 0; q < trips.size();) {
+        size_t e = q;
+        double s = 0.0;
+        while (e < trips.size() && trips[e].r == trips[q].r && trips[e].c == trips[q].c) s += trips[e++].v;
+        A.colidx.push_back(trips[q].c);
+        A.val.push_back(s);
+        A.rowptr[trips[q].r + 1] += 1;
+        if (trips[q].r == trips[q].c) A.diag[trips[q].r] = s;
+        q = e;
+    }
+    for (int64_t r = 0; r < A.n; ++r) A.rowptr[r + 1] += A.rowptr[r];
+}
+
+}  // namespace hmg

@@ -1,0 +1,139 @@
+/*
+ * hmg.h -- C ABI of libhmg_hip.so: matrix-free geometric multigrid on the implicit fine grid,
+ * MI355X (gfx950) native.  This is the drop-in boundary for the hot path (level L3) of
+ * haampie/Homogenization.jl.  The reference has no FFI seam; its seam is Julia multiple dispatch on
+ * `AbstractMatrix` level vectors (src/multigrid.jl:7-13).  Each entry point below names the reference
+ * method it replaces (file:line in the reference checkout).  A Julia host binds these with `ccall`
+ * (INTEGRATION.md); in this repository the executable host mirror is Python/ctypes
+ * (homogenization.jl_amd/api.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; hmg_last_error() gives the message
+ *     (thread-local).  No exception or longjmp crosses the boundary.
+ *   - handles are opaque, created and destroyed by the library.
+ *   - host arrays use the reference's API layout: level vectors are Nf x Ne column-major FP64 in
+ *     the reference's hierarchical node order (src/multilevel_reference.jl:41-61); meshes use
+ *     1-based node ids with every cell's tuple ascending (src/implicit_fine_grid.jl:14).
+ *   - device work is enqueued on the context's HIP stream; calls that return a scalar to the host
+ *     synchronise that stream, all others are asynchronous.
+ *   - all calls on one context must come from one host thread at a time.
+ */
+#ifndef HMG_H
+#define HMG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hmg_ctx hmg_ctx;
+typedef struct hmg_grid hmg_grid;
+typedef struct hmg_vec hmg_vec;
+
+const char *hmg_last_error(void);
+int hmg_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* stream: a hipStream_t owned by the caller (e.g. torch's current stream) or NULL to create one. */
+int hmg_ctx_create(int device, void *stream, hmg_ctx **out);
+int hmg_ctx_destroy(hmg_ctx *ctx);
+int hmg_ctx_sync(hmg_ctx *ctx);
+/* option names: "apply_variant" (0 generic, 1 persistent), "apply_threads", "coarse_maxit",
+ * "coarse_check" ; "coarse_rtol" via hmg_ctx_set_option_f64 */
+int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
+int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value);
+
+/* ---- grid: ImplicitFineGrid(base, levels)  (src/implicit_fine_grid.jl:13-18) ------------------ */
+/* Also derives ZeroDirichletConstraint(list_boundary_nodes_edges_faces(base)...)
+ * (src/interface.jl:207-284, src/implicit_fine_grid.jl:80-84). */
+int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords /* dim*nnodes */,
+                    int64_t ncells, const int64_t *cells /* (dim+1)*ncells, 1-based */, hmg_grid **out);
+int hmg_grid_destroy(hmg_grid *grid);
+/* L2PlusDivAGrad(diff, mass, constraint, lambda, sigmas)  (src/build_local_operators.jl:26-32) */
+int hmg_grid_set_operator(hmg_grid *grid, const double *sigma /* dim*ncells */, double lambda);
+int hmg_grid_set_lambda(hmg_grid *grid, double lambda);
+/* Domain shrink to a prefix of cells / nodes + new Dirichlet boundary
+ * (src/examples/homogenized_coefficients.jl:309-336).  Level vectors keep their storage. */
+int hmg_grid_shrink(hmg_grid *grid, int64_t ncells_prefix, int64_t nnodes_prefix);
+int64_t hmg_grid_ncells(const hmg_grid *grid);
+int64_t hmg_grid_nnodes(const hmg_grid *grid);
+int hmg_grid_nlevels(const hmg_grid *grid);
+int64_t hmg_grid_nf(const hmg_grid *grid, int level);   /* nnodes(refined_mesh(implicit, level)) */
+int64_t hmg_grid_ld(const hmg_grid *grid, int level);   /* device column stride in doubles */
+/* Table export for tests / host mirrors. which: "hier2slot" (int32[nf]), "slot_ijk" (int32[3*nf]),
+ * "slot_cls" (int32[nf]), "par_a","par_b" (int32[nf]), "ctab" (f64), "dmask","dupmask" (int32[ncells]),
+ * "interior_nodes" (int32, 0-based), "coef" (f64[8*ncells]).  Returns the element count via *count. */
+int hmg_grid_table_i32(const hmg_grid *grid, int level, const char *which, int32_t *out, int64_t cap, int64_t *count);
+int hmg_grid_table_f64(const hmg_grid *grid, int level, const char *which, double *out, int64_t cap, int64_t *count);
+
+/* ---- level vectors: the five matrices of LevelState (src/multigrid.jl:7-25) ------------------- */
+int hmg_vec_create(hmg_grid *grid, int level, hmg_vec **out);                 /* zeros(Nf, Ne) */
+int hmg_vec_wrap(hmg_grid *grid, int level, void *device_ptr, hmg_vec **out); /* caller-owned ld*Ne doubles */
+int hmg_vec_destroy(hmg_vec *v);
+void *hmg_vec_device_ptr(hmg_vec *v);
+int hmg_vec_upload(hmg_vec *v, const double *host);      /* Nf x Ne, hierarchical order */
+int hmg_vec_download(hmg_vec *v, double *host);
+int hmg_vec_fill(hmg_vec *v, double value);                                   /* fill!           */
+int hmg_vec_fill_random(hmg_vec *v, uint64_t seed, int64_t cell_offset);      /* rand! (seeded)  */
+int hmg_vec_copy(hmg_vec *dst, hmg_vec *src);                                 /* copyto!         */
+int hmg_vec_axpy(double alpha, hmg_vec *x, hmg_vec *y);                       /* axpy!  multigrid.jl:65-66 */
+int hmg_vec_xpby(hmg_vec *r, double beta, hmg_vec *p);                        /* p .= r .+ beta.*p  :68   */
+int hmg_vec_dot(hmg_vec *x, hmg_vec *y, double *out);    /* dot over raw storage, copies counted  :54 */
+int hmg_vec_norm_unique(hmg_vec *r, double *out);        /* norm after zero_out_all_but_one!, r kept */
+
+/* ---- hot-path primitives -------------------------------------------------------------------- */
+/* mul!(alpha, base, A::L2PlusDivAGrad, x, y): y += alpha*A*x   (src/apply_local_operators.jl:85-133) */
+int hmg_apply(hmg_grid *grid, int level, double alpha, hmg_vec *x, hmg_vec *y);
+/* local_residual!: r = b - A*x, then constraint            (src/apply_local_operators.jl:18-27) */
+int hmg_residual(hmg_grid *grid, int level, hmg_vec *x, hmg_vec *b, hmg_vec *r);
+/* apply_constraint!                                          (src/implicit_fine_grid.jl:94-139) */
+int hmg_constraint(hmg_grid *grid, int level, hmg_vec *x);
+/* broadcast_interfaces!                                      (src/implicit_fine_grid.jl:209-328) */
+int hmg_interface_sum(hmg_grid *grid, int level, hmg_vec *x);
+/* zero_out_all_but_one!                                      (src/implicit_fine_grid.jl:334-386) */
+int hmg_zero_duplicates(hmg_grid *grid, int level, hmg_vec *x);
+/* restrict_to!(b_coarse, P, r_fine) / interpolate_and_sum_to!(x_fine, P, x_coarse), P = interops[level_fine-1]
+ *                                                            (src/interpolation.jl:52-74) */
+int hmg_restrict(hmg_grid *grid, int level_fine, hmg_vec *r_fine, hmg_vec *b_coarse);
+int hmg_prolong_add(hmg_grid *grid, int level_fine, hmg_vec *x_coarse, hmg_vec *x_fine);
+/* copy_to_base! / distribute!                                (src/implicit_fine_grid.jl:148-202) */
+int hmg_gather_base(hmg_grid *grid, hmg_vec *v1, double *host_u /* nnodes */);
+int hmg_scatter_base(hmg_grid *grid, const double *host_u, hmg_vec *v1);
+
+/* ---- fused fast path ------------------------------------------------------------------------ */
+/* smoothing_steps!(steps, implicit, ops, curr, k)            (src/multigrid.jl:46-71) */
+int hmg_smooth(hmg_grid *grid, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap);
+/* Coarse operator for the current sigma/lambda/boundary: replaces
+ * cholesky(assemble_checkerboard(base, cond, lambda)[interior, interior])
+ * (src/examples/homogenized_coefficients.jl:259-261) by a device-resident Jacobi-PCG. */
+int hmg_coarse_setup(hmg_grid *grid);
+/* level-1 branch of vcycle!                                  (src/multigrid.jl:74-93) */
+int hmg_coarse_solve(hmg_grid *grid, hmg_vec *b1, hmg_vec *x1);
+int hmg_coarse_last_iterations(const hmg_grid *grid);
+/* vcycle!(implicit, base, ops, levels, k, steps); coarser levels use steps_coarse (the reference
+ * does not forward `steps`, src/multigrid.jl:109, so pass 2 for parity).
+ * states: 5*nlevels handles ordered level-major as x,b,r,p,Ap of level 1, then level 2, ... */
+int hmg_vcycle(hmg_grid *grid, int top_level, int steps, int steps_coarse, hmg_vec **states);
+
+/* ---- multi-GPU hooks (one process per GPU; the host layer owns the communicator) ------------------
+ * The grid of a rank holds the cells that rank owns.  Entities shared with other ranks are listed by
+ * hmg_grid_set_cut(): per cut entity a global cut id and the local first copy.  After the local
+ * interface sum the library packs one value per cut DOF into the exchange buffer, calls `exchange`
+ * (an in-place sum over ranks, e.g. RCCL allreduce issued by the host on the same stream) and writes
+ * the result back to every local copy.  `scalar_sum` does the same for `count` device doubles
+ * (the CG dot products). */
+typedef int (*hmg_exchange_fn)(void *user, void *device_buf, int64_t count);
+int hmg_grid_set_cut(hmg_grid *grid, int64_t ncut_global_faces, int64_t ncut_global_edges, int64_t ncut_global_nodes,
+                     int64_t nlocal_faces, const int64_t *face_gid, const int32_t *face_cell_lid,
+                     int64_t nlocal_edges, const int64_t *edge_gid, const int32_t *edge_cell_lid,
+                     int64_t nlocal_nodes, const int64_t *node_gid, const int32_t *node_cell_lid);
+int hmg_grid_set_exchange(hmg_grid *grid, hmg_exchange_fn exchange, hmg_exchange_fn scalar_sum, void *user,
+                          void *device_exchange_buf, int64_t exchange_buf_doubles);
+int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *grid, int level);
+void *hmg_ctx_scalar_bank(hmg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMG_H */

@@ -1,0 +1,221 @@
+"""
+CPU tests of the product's host-side tables (C++ in libhmg_hip.so, reached through the C ABI with a
+NULL context -- no device, no compute) against the oracle's literal restatement of the reference:
+hierarchical numbering, entity lists and orders, transfer tables, stencil tables, mesh masks,
+coarse matrix.  The stencil is evaluated here in numpy from the exported tables (test-side
+arithmetic, not a product code path).
+"""
+import numpy as np
+import pytest
+
+import homogenization_jl_amd as hmg
+
+DIRS3 = np.array([(0, 0, 0), (1, 0, 0), (-1, 0, 0), (-1, 1, 0), (1, -1, 0), (0, 1, 0), (0, -1, 0), (0, -1, 1),
+                  (0, 1, -1), (-1, 0, 1), (1, 0, -1), (0, 0, 1), (0, 0, -1), (1, -1, 1), (-1, 1, -1)])
+
+
+def small_mesh(O, dim, n=2, perturb=0.0, seed=0):
+    m = O.hypercube(dim, n)
+    if perturb:
+        rng = np.random.default_rng(seed)
+        m.nodes = m.nodes + perturb * (rng.random(m.nodes.shape) - 0.5)
+    return m
+
+
+def host_grid(m, levels):
+    return hmg.ImplicitFineGrid(None, hmg.Mesh(m.nodes, m.elements + 1), levels)
+
+
+@pytest.mark.parametrize("dim,levels", [(3, 6), (2, 7)])
+def test_numbering_and_entities(oracle, dim, levels):
+    O = oracle
+    ref = O.refined_element(levels, dim)
+    g = host_grid(small_mesh(O, dim, 1), levels)
+    for lev in range(1, levels + 1):
+        m = 2 ** (lev - 1)
+        nf = ref.levels[lev - 1].nnodes()
+        assert g.nf(lev) == nf
+        h2s = g.table_i32("hier2slot", lev)
+        ijk = g.table_i32("slot_ijk", lev).reshape(-1, 3)
+        lay = g.table_i32("layout", lev)
+        nfx, ld, ncorner, nedge, nface, nei, nfi, nint, off_edge, off_face, off_int = lay[:11]
+        assert sorted(h2s) == list(range(nf))
+        # lattice coordinates of every hierarchical node match the literally refined mesh
+        want = np.round(ref.levels[lev - 1].nodes * m).astype(int)
+        np.testing.assert_array_equal(ijk[h2s][:, :dim], want)
+        nb = ref.numbering[lev - 1]
+        # entity-major storage: every entity is one contiguous run in the reference's list order
+        np.testing.assert_array_equal(h2s[nb.nodes], np.arange(dim + 1))
+        for e, lst in enumerate(nb.edges_interior):
+            np.testing.assert_array_equal(h2s[lst], off_edge + e * nei + np.arange(len(lst)))
+            assert len(lst) == nei
+        if dim == 3:
+            for f, lst in enumerate(nb.faces_interior):
+                np.testing.assert_array_equal(h2s[lst], off_face + f * nfi + np.arange(len(lst)))
+                assert len(lst) == nfi
+
+
+@pytest.mark.parametrize("dim,levels", [(3, 5), (2, 6)])
+def test_transfer_tables(oracle, dim, levels):
+    O = oracle
+    ref = O.refined_element(levels, dim)
+    g = host_grid(small_mesh(O, dim, 1), levels)
+    rng = np.random.default_rng(0)
+    for lev in range(2, levels + 1):
+        P = ref.interops[lev - 2]
+        h2s_f, h2s_c = g.table_i32("hier2slot", lev), g.table_i32("hier2slot", lev - 1)
+        pa, pb = g.table_i32("par_a", lev), g.table_i32("par_b", lev)
+        xc = rng.random(P.shape[1])
+        xc_s = np.zeros_like(xc); xc_s[h2s_c] = xc
+        yf_s = np.where(pa == pb, xc_s[pa], 0.5 * xc_s[pa] + 0.5 * xc_s[pb])
+        np.testing.assert_allclose(yf_s[h2s_f], P @ xc, rtol=0, atol=1e-15)
+        # parent order = CSC column order (smaller hierarchical id first)
+        s2h_c = np.argsort(h2s_c)
+        assert np.all(s2h_c[pa] <= s2h_c[pb])
+        rptr, ridx = g.table_i32("rptr", lev), g.table_i32("ridx", lev)
+        xf = rng.random(P.shape[0])
+        xf_s = np.zeros_like(xf); xf_s[h2s_f] = xf
+        bc_s = np.array([xf_s[ridx[rptr[c]]] + 0.5 * xf_s[ridx[rptr[c] + 1:rptr[c + 1]]].sum()
+                         for c in range(P.shape[1])])
+        np.testing.assert_allclose(bc_s[h2s_c], P.T @ xf, rtol=0, atol=1e-14)
+
+
+def eval_stencil(g, lev, dim, coef, alpha, lam, x_slots):
+    """numpy evaluation of the exported class stencil for every cell: y (nf, ne) in slot order."""
+    ndir = 15 if dim == 3 else 7
+    nterm = 7 if dim == 3 else 4
+    ijk = g.table_i32("slot_ijk", lev).reshape(-1, 3)
+    cls = g.table_i32("slot_cls", lev)
+    ctab = g.table_f64("ctab", lev).reshape(-1, ndir, nterm)
+    m = g.table_i32("layout", lev)[16]
+    nf, ne = x_slots.shape
+    at = -np.ones((m + 3, m + 3, m + 3), dtype=int)
+    at[ijk[:, 0] + 1, ijk[:, 1] + 1, ijk[:, 2] + 1] = np.arange(nf)
+    y = np.zeros_like(x_slots)
+    s = coef.reshape(-1, 8)[:, :nterm].copy() * alpha
+    s[:, nterm - 1] *= lam
+    W = np.einsum("cdt,et->ecd", ctab, s)                      # (ne, ncls, ndir)
+    for d in range(ndir):
+        nb = at[ijk[:, 0] + 1 + DIRS3[d, 0], ijk[:, 1] + 1 + DIRS3[d, 1], ijk[:, 2] + 1 + DIRS3[d, 2]]
+        ok = nb >= 0
+        w = W[:, cls, d].T                                       # (nf, ne)
+        assert np.all(w[~ok] == 0.0)                             # out-of-cell taps carry zero weight
+        y[ok] += w[ok] * x_slots[nb[ok]]
+    return y
+
+
+@pytest.mark.parametrize("dim,levels,n", [(3, 4, 2), (3, 5, 1), (2, 5, 3)])
+def test_stencil_tables_match_reference_apply(oracle, dim, levels, n):
+    """class-form lattice stencil == the reference's dim^2+1 CSC scatter passes, on a perturbed mesh."""
+    O = oracle
+    m = small_mesh(O, dim, n, perturb=0.3, seed=4)
+    rng = np.random.default_rng(5)
+    sig = rng.choice([1.0, 9.0], size=(m.nelements(), dim))
+    lam, alpha = 0.7, -1.3
+    g = host_grid(m, levels)
+    g.set_operator(sig, lam)
+    coef = g.table_f64("coef")
+    impl = O.ImplicitFineGrid.create(m, levels)
+    for lev in range(1, levels + 1):
+        lvl = impl.reference.levels[lev - 1]
+        A = O.L2PlusDivAGrad(O.build_local_diffusion_operators(lvl), O.mass_matrix(lvl), None, lam, sig)
+        nf = impl.nf(lev)
+        x = np.asfortranarray(rng.standard_normal((nf, m.nelements())))
+        y = np.zeros_like(x, order="F")
+        O.mul(alpha, m, A, x, y)
+        h2s = g.table_i32("hier2slot", lev)
+        xs = np.zeros_like(x); xs[h2s] = x
+        ys = eval_stencil(g, lev, dim, coef, alpha, lam, xs)
+        scale = np.abs(y).max()
+        assert np.abs(ys[h2s] - y).max() <= 1e-13 * scale
+
+
+def test_mesh_masks_and_lists(oracle):
+    O = oracle
+    m = O.order_nodes_and_elements_by_magnitude(O.hypercube(3, 4, origin=(-2.0, -2.0, -2.0)))
+    levels = 3
+    g = host_grid(m, levels)
+    impl = O.ImplicitFineGrid.create(m, levels)
+    cn, ce, cf = O.list_boundary_nodes_edges_faces(m)
+    nface, nedge = 4, 6
+    want = np.zeros(m.nelements(), dtype=np.int64)
+    np.bitwise_or.at(want, cf.element, 1 << cf.local_id)
+    np.bitwise_or.at(want, ce.element, 1 << (nface + ce.local_id))
+    np.bitwise_or.at(want, cn.element, 1 << (nface + nedge + cn.local_id))
+    np.testing.assert_array_equal(g.table_i32("dmask"), want)
+    # duplicate mask: copies 2..n of each shared entity
+    inter = impl.interfaces
+    dup = np.zeros(m.nelements(), dtype=np.int64)
+    for smap, shift in ((inter.faces, 0), (inter.edges, nface), (inter.nodes, nface + nedge)):
+        first = np.zeros(len(smap.element), dtype=bool)
+        first[smap.offset[:-1]] = True
+        np.bitwise_or.at(dup, smap.element[~first], 1 << (shift + smap.local_id[~first]))
+    np.testing.assert_array_equal(g.table_i32("dupmask"), dup)
+    # shared lists keep the reference's copy order (ascending cell)
+    fp = g.table_i32("face_pairs").reshape(-1, 3)
+    assert fp.shape[0] == len(inter.faces)
+    np.testing.assert_array_equal(fp[:, 0], inter.faces.element[inter.faces.offset[:-1]])
+    np.testing.assert_array_equal(fp[:, 1], inter.faces.element[inter.faces.offset[:-1] + 1])
+    np.testing.assert_array_equal(fp[:, 2] & 15, inter.faces.local_id[inter.faces.offset[:-1]])
+    np.testing.assert_array_equal(fp[:, 2] >> 4, inter.faces.local_id[inter.faces.offset[:-1] + 1])
+    np.testing.assert_array_equal(g.table_i32("edge_ptr"), inter.edges.offset)
+    np.testing.assert_array_equal(g.table_i32("edge_ent"), inter.edges.element * 8 + inter.edges.local_id)
+    np.testing.assert_array_equal(g.table_i32("node_ptr"), inter.nodes.offset)
+    np.testing.assert_array_equal(g.table_i32("node_ent"), inter.nodes.element * 8 + inter.nodes.local_id)
+    an = inter.all_nodes
+    np.testing.assert_array_equal(g.table_i32("node_first"),
+                                  an.element[an.offset[:-1]] * 8 + an.local_id[an.offset[:-1]])
+    np.testing.assert_array_equal(g.interior_nodes(), O.list_interior_nodes(m))
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_coarse_matrix(oracle, dim):
+    import scipy.sparse as sp
+    O = oracle
+    m = small_mesh(O, dim, 3, perturb=0.2, seed=1)
+    rng = np.random.default_rng(2)
+    sig = rng.choice([1.0, 9.0], size=(m.nelements(), dim))
+    g = host_grid(m, 2)
+    g.set_operator(sig, 0.35)
+    g.coarse_setup()
+    interior = O.list_interior_nodes(m)
+    want = O.assemble_checkerboard(m, sig, 0.35).tocsr()[interior][:, interior]
+    got = sp.csr_matrix((g.table_f64("coarse_val"), g.table_i32("coarse_colidx"), g.table_i32("coarse_rowptr")),
+                        shape=want.shape)
+    assert abs(got - want).max() <= 1e-13 * abs(want).max()
+
+
+def test_shrink_rebuilds_boundary(oracle):
+    O = oracle
+    m = O.order_nodes_and_elements_by_magnitude(O.hypercube(3, 6, origin=(-3.0, -3.0, -3.0)))
+    g = host_grid(m, 2)
+    ne = O.find_elements_in_radius(m, 2)
+    nn = O.find_nodes_in_radius(m, 2)
+    g.shrink(ne, nn)
+    sub = O.Mesh(m.nodes[:nn], m.elements[:ne])
+    assert g.ncells() == ne and g.nnodes_base() == nn
+    np.testing.assert_array_equal(g.interior_nodes(), O.list_interior_nodes(sub))
+
+
+def test_library_exports_every_declared_symbol():
+    import re, os
+    from importlib import import_module
+    lib = hmg._lib.load()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hmg.h")).read()
+    declared = set(re.findall(r"\b(hmg_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"hmg_exchange_fn"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/hmg.h but not exported"
+        assert name in hmg._lib.SIGNATURES, f"{name} has no ctypes signature"
+
+
+def test_no_cpu_compute_path():
+    """Without a device context there is no compute: the library refuses, it does not fall back."""
+    import ctypes
+    lib = hmg._lib.load()
+    h = ctypes.c_void_p()
+    rc = lib.hmg_ctx_create(0, None, ctypes.byref(h))
+    import torch
+    if not torch.cuda.is_available():
+        assert rc != 0 and b"no CPU fallback" in lib.hmg_last_error()
