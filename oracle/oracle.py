@@ -51,7 +51,17 @@ def _p(a):
 def build_lib(force: bool = False) -> str:
     """Compile oracle/hmg_oracle.c -> oracle/libhmg_oracle.so (gcc -O3 -fopenmp)."""
     src = os.path.join(_HERE, "hmg_oracle.c")
-    out = os.path.join(_HERE, "libhmg_oracle.so")
+    # -march=native code is host specific: key the file name on the CPU's feature flags so a
+    # snapshot built elsewhere is rebuilt instead of faulting with an illegal instruction.
+    tag = "generic"
+    try:
+        import hashlib
+        with open("/proc/cpuinfo") as f:
+            flags = next((l for l in f if l.startswith("flags")), "")
+        tag = hashlib.sha1(flags.encode()).hexdigest()[:10]
+    except OSError:
+        pass
+    out = os.path.join(_HERE, f"libhmg_oracle_{tag}.so")
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         subprocess.check_call(
             ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11",

@@ -1,0 +1,281 @@
+"""
+GPU parity tests: every hot-path primitive of libhmg_hip.so (through the C ABI / Python host mirror)
+against the CPU oracle on identical seeded inputs.  FP64 tolerances (stated per test):
+  per primitive   rel max-norm error <= 1e-11   
+  interface sum / masks / transfer of exact data: bit-exact where the operation order is the
+  reference's (copies summed in ascending cell order).
+"""
+import numpy as np
+import pytest
+
+import homogenization_jl_amd as hmg
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hmg.Context(0)
+    yield c
+    c.close()
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+class Case:
+    """A small configuration shared by oracle and device."""
+
+    def __init__(self, O, ctx, dim, n, levels, lam=0.7, perturb=0.0, seed=0, ordered=True):
+        self.O, self.dim, self.levels, self.lam = O, dim, levels, lam
+        m = O.hypercube(dim, n, origin=(-n / 2.0,) * dim)
+        if ordered:
+            m = O.order_nodes_and_elements_by_magnitude(m)
+        rng = np.random.default_rng(seed)
+        if perturb:
+            m.nodes = m.nodes + perturb * (rng.random(m.nodes.shape) - 0.5)
+        self.mesh = m
+        self.sig = rng.choice([1.0, 9.0], size=(m.nelements(), dim))
+        self.impl = O.ImplicitFineGrid.create(m, levels)
+        self.cons = O.ZeroDirichletConstraint(*O.list_boundary_nodes_edges_faces(m))
+        self.ops = [O.L2PlusDivAGrad(O.build_local_diffusion_operators(l), O.mass_matrix(l), self.cons, lam, self.sig)
+                    for l in self.impl.reference.levels]
+        self.g = hmg.ImplicitFineGrid(ctx, hmg.Mesh(m.nodes, m.elements + 1), levels)
+        self.A = hmg.L2PlusDivAGrad(self.g, lam, self.sig)
+        self.rng = rng
+
+    def rand(self, level):
+        return np.asfortranarray(self.rng.standard_normal((self.impl.nf(level), self.mesh.nelements())))
+
+    def dev(self, level, a):
+        return hmg.DeviceMatrix(self.g, level).from_host(a)
+
+
+@pytest.fixture(scope="module")
+def case3(oracle, ctx):
+    return Case(oracle, ctx, 3, 4, 5, perturb=0.2, seed=1)
+
+
+@pytest.fixture(scope="module")
+def case2(oracle, ctx):
+    return Case(oracle, ctx, 2, 6, 6, perturb=0.2, seed=2)
+
+
+def test_upload_download_roundtrip(case3):
+    c = case3
+    for lev in range(1, c.levels + 1):
+        a = c.rand(lev)
+        np.testing.assert_array_equal(c.dev(lev, a).to_host(), a)
+
+
+def test_device_rand_matches_host_twin(case3):
+    c = case3
+    d = hmg.DeviceMatrix(c.g, c.levels).rand(1234, cell_offset=5)
+    np.testing.assert_array_equal(d.to_host(), hmg.host_random(d.shape, 1234, 5))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("which", ["case3", "case2"])
+def test_apply_matches_oracle(request, ctx, which, variant):
+    """mul!(alpha, base, A, x, y) -- ref: src/apply_local_operators.jl:85-133"""
+    c = request.getfixturevalue(which)
+    ctx.set_option("apply_variant", variant)
+    try:
+        for lev in range(1, c.levels + 1):
+            x, y = c.rand(lev), c.rand(lev)
+            want = y.copy(order="F")
+            c.O.mul(-1.3, c.mesh, c.ops[lev - 1], x, want)
+            dx, dy = c.dev(lev, x), c.dev(lev, y)
+            hmg.mul(-1.3, c.g, c.A, dx, dy)
+            assert relerr(dy.to_host(), want) <= TOL, (which, lev)
+    finally:
+        ctx.set_option("apply_variant", 1)
+
+
+@pytest.mark.parametrize("which", ["case3", "case2"])
+def test_residual_and_constraint(request, which):
+    """local_residual! / apply_constraint! -- ref: src/apply_local_operators.jl:18-27, src/implicit_fine_grid.jl:94-139"""
+    c = request.getfixturevalue(which)
+    O = c.O
+    for lev in range(2, c.levels + 1):
+        st = O.LevelState.create(c.mesh.nelements(), c.impl.nf(lev))
+        st.x[...] = c.rand(lev); st.b[...] = c.rand(lev)
+        O.local_residual(c.impl, c.ops[lev - 1], st, lev)
+        dst = hmg.LevelState(c.g, lev)
+        dst.x.from_host(st.x); dst.b.from_host(st.b)
+        hmg.local_residual(c.g, c.A, dst, lev)
+        got = dst.r.to_host()
+        assert relerr(got, st.r) <= TOL
+        np.testing.assert_array_equal(got == 0.0, st.r == 0.0)          # same Dirichlet zero pattern
+        a = c.rand(lev)
+        want = a.copy(order="F"); O.apply_constraint(want, lev, c.cons, c.impl)
+        d = c.dev(lev, a); hmg.apply_constraint(d, lev, c.g)
+        np.testing.assert_array_equal(d.to_host(), want)
+
+
+@pytest.mark.parametrize("which", ["case3", "case2"])
+def test_interface_sum_and_duplicates_bit_exact(request, which):
+    """broadcast_interfaces! / zero_out_all_but_one! -- ref: src/implicit_fine_grid.jl:209-386"""
+    c = request.getfixturevalue(which)
+    O = c.O
+    for lev in range(1, c.levels + 1):
+        a = c.rand(lev)
+        want = a.copy(order="F"); O.broadcast_interfaces(want, c.impl, lev)
+        d = c.dev(lev, a); hmg.broadcast_interfaces(d, c.g, lev)
+        np.testing.assert_array_equal(d.to_host(), want)                # same copy order => same bits
+        want2 = want.copy(order="F"); O.zero_out_all_but_one(want2, c.impl, lev)
+        n_unique = hmg.norm_unique(d)
+        assert abs(n_unique - np.linalg.norm(want2)) <= 1e-13 * np.linalg.norm(want2)
+        hmg.zero_out_all_but_one(d, c.g, lev)
+        np.testing.assert_array_equal(d.to_host(), want2)
+
+
+@pytest.mark.parametrize("which", ["case3", "case2"])
+def test_transfer(request, which):
+    """restrict_to! / interpolate_and_sum_to! -- ref: src/interpolation.jl:52-74"""
+    c = request.getfixturevalue(which)
+    O = c.O
+    for lev in range(2, c.levels + 1):
+        P = c.impl.reference.interops[lev - 2]
+        xf, xc = c.rand(lev), c.rand(lev - 1)
+        want = xf.copy(order="F"); O.interpolate_and_sum_to(want, P, xc)
+        df, dc = c.dev(lev, xf), c.dev(lev - 1, xc)
+        hmg.interpolate_and_sum_to(df, c.g, dc)
+        np.testing.assert_array_equal(df.to_host(), want)               # same operation order
+        wantb = np.zeros_like(xc, order="F"); O.restrict_to(wantb, P, xf)
+        db = hmg.DeviceMatrix(c.g, lev - 1)
+        hmg.restrict_to(db, c.g, c.dev(lev, xf))
+        assert relerr(db.to_host(), wantb) <= 1e-15 * 16
+
+
+def test_affine_reproduction_under_prolongation(oracle, ctx):
+    """ref: test/interpolation.jl:8-35, on the device path"""
+    O = oracle
+    c = Case(O, ctx, 3, 2, 6, lam=1.0, seed=3, ordered=False)
+    direction = np.array([0.3, -1.1, 0.7])
+    u = 10.0 + c.mesh.nodes @ direction
+    v = hmg.DeviceMatrix(c.g, 1)
+    hmg.distribute(v, u, c.g)
+    np.testing.assert_array_equal(hmg.copy_to_base(c.g, v), u)
+    for lev in range(2, 7):
+        nxt = hmg.DeviceMatrix(c.g, lev).fill(0.0)
+        hmg.interpolate_and_sum_to(nxt, c.g, v)
+        v = nxt
+        full = c.impl.construct_full_grid(lev)
+        np.testing.assert_allclose(v.to_host().T, 10.0 + full @ direction, rtol=1e-13)
+
+
+def test_blas1(case3):
+    c = case3
+    lev = c.levels
+    a, b = c.rand(lev), c.rand(lev)
+    da, db = c.dev(lev, a), c.dev(lev, b)
+    assert abs(hmg.dot(da, db) - float(np.vdot(a, b))) <= 1e-12 * np.linalg.norm(a) * np.linalg.norm(b)
+    hmg.axpy(0.37, da, db)
+    np.testing.assert_allclose(db.to_host(), b + 0.37 * a, rtol=0, atol=1e-15 * 8)
+    hmg.xpby(da, -1.7, db)
+    np.testing.assert_allclose(db.to_host(), a - 1.7 * (b + 0.37 * a), rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("which", ["case3", "case2"])
+def test_gather_scatter_base(request, which):
+    """copy_to_base! / distribute! -- ref: src/implicit_fine_grid.jl:148-202"""
+    c = request.getfixturevalue(which)
+    O = c.O
+    a = c.rand(1)
+    u = np.zeros(c.mesh.nnodes()); O.copy_to_base(u, a, c.impl)
+    np.testing.assert_array_equal(hmg.copy_to_base(c.g, c.dev(1, a)), u)
+    w = c.rng.standard_normal(c.mesh.nnodes())
+    want = np.zeros_like(a, order="F"); O.distribute(want, w, c.impl)
+    d = hmg.DeviceMatrix(c.g, 1); hmg.distribute(d, w, c.g)
+    np.testing.assert_array_equal(d.to_host(), want)
+
+
+def _oracle_state(c, lev):
+    O = c.O
+    st = O.LevelState.create(c.mesh.nelements(), c.impl.nf(lev))
+    st.x[...] = c.rand(lev)
+    O.broadcast_interfaces(st.x, c.impl, lev)
+    O.apply_constraint(st.x, lev, c.cons, c.impl)
+    st.b[...] = c.rand(lev)
+    return st
+
+
+@pytest.mark.parametrize("which", ["case3", "case2"])
+def test_smoothing_steps(request, which):
+    """smoothing_steps! (CG, duplicate-counting dots) -- ref: src/multigrid.jl:46-71. tol 1e-10 on x, r."""
+    c = request.getfixturevalue(which)
+    lev = c.levels
+    st = _oracle_state(c, lev)
+    dst = hmg.LevelState(c.g, lev)
+    dst.x.from_host(st.x); dst.b.from_host(st.b)
+    c.O.smoothing_steps(3, c.impl, c.ops[lev - 1], st, lev)
+    hmg.smoothing_steps(3, c.g, c.A, dst, lev)
+    assert relerr(dst.x.to_host(), st.x) <= 1e-10
+    assert relerr(dst.r.to_host(), st.r) <= 1e-10
+    assert relerr(dst.p.to_host(), st.p) <= 1e-10
+
+
+@pytest.mark.parametrize("which,dim,n,levels", [("3d", 3, 4, 4), ("2d", 2, 8, 5)])
+def test_vcycle_matches_oracle(oracle, ctx, which, dim, n, levels):
+    """vcycle! incl. coarse solve -- ref: src/multigrid.jl:73-119.  x after one and three V-cycles: rel 1e-9."""
+    O = oracle
+    c = Case(O, ctx, dim, n, levels, lam=1.0, seed=11)
+    sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(levels)]
+    top = _oracle_state(c, levels)
+    sts[-1] = top
+    dsts = [hmg.LevelState(c.g, i + 1) for i in range(levels)]
+    dsts[-1].x.from_host(top.x); dsts[-1].b.from_host(top.b)
+    base = O.make_base_level(c.mesh, c.sig, 1.0)
+    dbase = hmg.BaseLevel(c.g)
+    norms = []
+    for cyc in range(3):
+        O.vcycle(c.impl, base, c.ops, sts, levels, 3)
+        hmg.vcycle(c.g, dbase, [c.A] * levels, dsts, levels, 3)
+        assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9, (which, cyc)
+        r = sts[-1].r.copy(order="F"); O.zero_out_all_but_one(r, c.impl, levels)
+        norms.append((np.linalg.norm(r), hmg.norm_unique(dsts[-1].r)))
+    for a, b in norms:
+        assert abs(a - b) <= 1e-8 * a
+    assert norms[-1][0] < 0.2 * norms[0][0]                              # multigrid contracts
+    assert dbase.last_iterations() > 0
+
+
+def test_shrink_then_vcycle(oracle, ctx):
+    """Domain shrink (prefix of cells/nodes + new boundary) then a V-cycle -- ref: ...homogenized_coefficients.jl:309-336"""
+    O = oracle
+    c = Case(O, ctx, 3, 6, 3, lam=0.5, seed=5)
+    ne = O.find_elements_in_radius(c.mesh, 2)
+    nn = O.find_nodes_in_radius(c.mesh, 2)
+    sub = O.Mesh(c.mesh.nodes[:nn], np.ascontiguousarray(c.mesh.elements[:ne]))
+    sig = np.ascontiguousarray(c.sig[:ne])
+    impl = O.ImplicitFineGrid.create(sub, 3)
+    cons = O.ZeroDirichletConstraint(*O.list_boundary_nodes_edges_faces(sub))
+    ops = [O.L2PlusDivAGrad(O.build_local_diffusion_operators(l), O.mass_matrix(l), cons, 0.5, sig)
+           for l in impl.reference.levels]
+    x_full = c.rand(3); b_full = c.rand(3)
+    dsts = [hmg.LevelState(c.g, i + 1) for i in range(3)]
+    dsts[-1].x.from_host(x_full); dsts[-1].b.from_host(b_full)
+    c.g.shrink(ne, nn)
+    hmg.broadcast_interfaces(dsts[-1].x, c.g, 3)
+    hmg.apply_constraint(dsts[-1].x, 3, c.g)
+    sts = [O.LevelState.create(ne, impl.nf(i + 1)) for i in range(3)]
+    sts[-1].x[...] = x_full[:, :ne]; sts[-1].b[...] = b_full[:, :ne]
+    O.broadcast_interfaces(sts[-1].x, impl, 3)
+    O.apply_constraint(sts[-1].x, 3, cons, impl)
+    O.vcycle(impl, O.make_base_level(sub, sig, 0.5), ops, sts, 3, 3)
+    hmg.vcycle(c.g, hmg.BaseLevel(c.g), [c.A] * 3, dsts, 3, 3)
+    assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9
+
+
+def test_errors_are_reported_not_thrown(case3):
+    c = case3
+    a = hmg.DeviceMatrix(c.g, 2)
+    b = hmg.DeviceMatrix(c.g, 3)
+    with pytest.raises(hmg._lib.HmgError):
+        hmg.mul(1.0, c.g, c.A, a, b)          # level mismatch
+    with pytest.raises(hmg._lib.HmgError):
+        hmg.mul(1.0, c.g, c.A, b, b)          # aliasing
