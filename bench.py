@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""
+bench.py -- fine-DOF updates/s per V-cycle on the 3D Tet64 checkerboard (BASELINE.json metric).
+
+One "step" = one `vcycle!(implicit, base, ops, levels, L, 3)` (3 CG smoothing steps on the finest level,
+2 on the coarser ones as in the reference, coarse solve and all interface sums included) over
+BASELINE config 3: 32^3 unit cubes x 6 tets, refinements=5 (L=6, Nf=6545, 1.287e9 fine DOFs), FP64,
+synthetic seeded inputs already resident in HBM.  value = Nf_L * Ne / t_vcycle, whole job.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): the mesh
+grows with N (weak scaling, 32^3 cubes per GPU) and is partitioned by coarse-cell ownership.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0    # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def cpu_baseline(sample_width, levels, steps_top):
+    """The oracle (CPU restatement of the reference algorithm, reference threading structure) timed on
+    this host: one V-cycle on a sample_width^3-cube sub-domain of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+    m = O.order_nodes_and_elements_by_magnitude(
+        O.hypercube(3, sample_width, origin=(-sample_width / 2.0,) * 3))
+    rng = np.random.default_rng(0)
+    sig = rng.choice([1.0, 9.0], size=(m.nelements(), 3))
+    impl = O.ImplicitFineGrid.create(m, levels)
+    cons = O.ZeroDirichletConstraint(*O.list_boundary_nodes_edges_faces(m))
+    ops = [O.L2PlusDivAGrad(O.build_local_diffusion_operators(l), O.mass_matrix(l), cons, 1.0, sig)
+           for l in impl.reference.levels]
+    st = [O.LevelState.create(m.nelements(), impl.nf(i + 1)) for i in range(levels)]
+    st[-1].x[...] = rng.random(st[-1].x.shape)
+    O.broadcast_interfaces(st[-1].x, impl, levels)
+    O.apply_constraint(st[-1].x, levels, cons, impl)
+    dphis = O.partial_derivatives_functionals(impl.reference.levels[-1])
+    O.rhs_axi_grad_v(st[-1].b, dphis, impl, sig, np.ones(3) / np.sqrt(3.0))
+    base = O.make_base_level(m, sig, 1.0)
+    threads = O.lib().orc_max_threads()
+    t0 = time.perf_counter()
+    O.vcycle(impl, base, ops, st, levels, steps_top)
+    dt = time.perf_counter() - t0
+    dofs = impl.nf(levels) * m.nelements()
+    return {"value": dofs / dt, "unit": "fine-DOF updates/s per V-cycle", "cores": int(threads), "kind": "port",
+            "sample": f"1 V-cycle of the oracle (C restatement, cyclic cell distribution over {threads} OpenMP "
+                      f"threads, serial interface sum) on a {sample_width}^3-cube sub-domain "
+                      f"({m.nelements()} of the workload's cells), L={levels}, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=32, help="unit cubes per axis per GPU")
+    ap.add_argument("--levels", type=int, default=6, help="refinements + 1")
+    ap.add_argument("--smoothing-steps", type=int, default=3)
+    ap.add_argument("--cpu-sample-width", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--apply-variant", type=int, default=None)
+    ap.add_argument("--apply-threads", type=int, default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import homogenization_jl_amd as hmg
+    from homogenization_jl_amd import driver
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = hmg.Context(local_rank, stream=stream)
+    if args.apply_variant is not None:
+        ctx.set_option("apply_variant", args.apply_variant)
+    if args.apply_threads is not None:
+        ctx.set_option("apply_threads", args.apply_threads)
+
+    L = args.levels
+    w = args.width
+    if world > 1:
+        from homogenization_jl_amd import dist as hdist
+        prob = hdist.partitioned_checkerboard(ctx, w, L, world, rank, seed=0)
+        base, cond, implicit, op = prob.base, prob.cond, prob.implicit, prob.op
+        workload = f"3D Tet64 checkerboard, {prob.global_shape} unit cubes over {world} GPUs ({w}^3 per GPU), refinements={L - 1}"
+    else:
+        base, cond, implicit, op = driver.checkerboard_problem(ctx, hmg.Tet64, w, L, seed=0)
+        workload = f"3D Tet64 checkerboard, {w}^3 unit cubes x 6 tets, refinements={L - 1} (BASELINE config 3)"
+    ne_local = implicit.ncells()
+    nf = implicit.nf(L)
+
+    states = [hmg.LevelState(implicit, i + 1) for i in range(L)]
+    top = states[-1]
+    top.x.rand(1234, cell_offset=rank * ne_local)
+    hmg.broadcast_interfaces(top.x, implicit, L)
+    hmg.apply_constraint(top.x, L, implicit)
+    hmg.rhs_axi_grad_v(top.b, implicit, driver.random_unit_vec(3))
+    base_level = hmg.BaseLevel(implicit) if world == 1 else prob.base_level()
+    ops = [op] * L
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
+    barrier()
+    ctx.set_option("time_apply", L)          # HIP events around the finest-level operator applies
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    launches, ms, nbytes = ctx.apply_timing()
+    ctx.set_option("time_apply", 0)
+    rnorm = hmg.norm_unique(top.r) if world == 1 else float("nan")
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([float(ne_local)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot)
+        ne_total = int(tot.item())
+    else:
+        ne_total = ne_local
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        value = nf * ne_total * args.steps / dt
+        avg_ms = ms / max(launches, 1)
+        achieved = (nbytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "apply_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fine-DOF updates/sec per V-cycle (3D Tet64)",
+            "value": value,
+            "unit": "fine-DOF updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (seeded checkerboard sigma in {1,9}, hashed x0, b = rhs_a.xi.grad(v), lambda=1)",
+            "config": {"workload": workload, "cells": ne_total, "nf": nf, "levels": L,
+                       "smoothing_steps": args.smoothing_steps, "smoothing_steps_coarse": 2,
+                       "coarse_solver": "device Jacobi-PCG rtol 1e-13",
+                       "coarse_iterations_last": base_level.last_iterations() if world == 1 else None,
+                       "residual_norm_after": rnorm},
+            "roofline": {"bound": "hbm", "kernel": "k_apply_persist (finest-level operator apply)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches": int(launches), "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": nbytes / max(launches, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_width, L, args.smoothing_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

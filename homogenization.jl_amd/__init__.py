@@ -3,3 +3,4 @@ haampie/Homogenization.jl behind the reference's own interface.  See DESIGN.md /
 from . import _lib  # noqa: F401
 from .api import *  # noqa: F401,F403
 from . import api  # noqa: F401
+from . import driver  # noqa: F401

@@ -27,6 +27,9 @@ SIGNATURES = {
     "hmg_ctx_set_option": (c_int, [vp, ctypes.c_char_p, c_i64]),
     "hmg_ctx_set_option_f64": (c_int, [vp, ctypes.c_char_p, c_f64]),
     "hmg_ctx_scalar_bank": (vp, [vp]),
+    "hmg_ctx_apply_timing": (c_int, [vp, p_i64, p_f64, p_f64]),
+    "hmg_rhs_axi_grad": (c_int, [vp, p_f64, vp]),
+    "hmg_next_rhs": (c_int, [vp, vp, vp]),
     "hmg_grid_create": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, pp]),
     "hmg_grid_destroy": (c_int, [vp]),
     "hmg_grid_set_operator": (c_int, [vp, p_f64, c_f64]),
@@ -53,6 +56,7 @@ SIGNATURES = {
     "hmg_vec_dot": (c_int, [vp, vp, p_f64]),
     "hmg_vec_norm_unique": (c_int, [vp, p_f64]),
     "hmg_apply": (c_int, [vp, c_int, c_f64, vp, vp]),
+    "hmg_apply_ex": (c_int, [vp, c_int, c_f64, vp, vp, vp, c_int]),
     "hmg_residual": (c_int, [vp, c_int, vp, vp, vp]),
     "hmg_constraint": (c_int, [vp, c_int, vp]),
     "hmg_interface_sum": (c_int, [vp, c_int, vp]),

@@ -66,6 +66,15 @@ class Context:
         else:
             L.check(self._lib.hmg_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def apply_timing(self):
+        """(launches, total_ms, algorithmic_bytes) of the operator applies timed since option
+        "time_apply" was last set."""
+        n = ctypes.c_int64()
+        ms = ctypes.c_double()
+        by = ctypes.c_double()
+        L.check(self._lib.hmg_ctx_apply_timing(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+        return n.value, ms.value, by.value
+
     def close(self):
         if self.h:
             self._lib.hmg_ctx_destroy(self.h)
@@ -274,6 +283,12 @@ def mul(alpha, implicit: ImplicitFineGrid, A: L2PlusDivAGrad, x: DeviceMatrix, y
     L.check(L.load().hmg_apply(implicit.h, x.level, float(alpha), x.h, y.h))
 
 
+def apply_ex(alpha, implicit: ImplicitFineGrid, x: DeviceMatrix, src, out: DeviceMatrix, constrain=False):
+    """out = (src or 0) + alpha*A*x, optionally followed by the Dirichlet constraint (one fused kernel)."""
+    L.check(L.load().hmg_apply_ex(implicit.h, x.level, float(alpha), x.h, src.h if src is not None else None, out.h,
+                                  1 if constrain else 0))
+
+
 def local_residual(implicit, A, curr: LevelState, k: int):
     L.check(L.load().hmg_residual(implicit.h, k, curr.x.h, curr.b.h, curr.r.h))
 
@@ -308,6 +323,18 @@ def copy_to_base(implicit: ImplicitFineGrid, v1: DeviceMatrix):
 def distribute(v1: DeviceMatrix, u, implicit: ImplicitFineGrid):
     u = np.ascontiguousarray(u, dtype=np.float64)
     L.check(L.load().hmg_scatter_base(implicit.h, u.ctypes.data_as(L.p_f64), v1.h))
+
+
+def rhs_axi_grad_v(b: DeviceMatrix, implicit: ImplicitFineGrid, xi):
+    """rhs_a xi grad v!(b, dphis, implicit, sigmas, xi): b[i, el] = dot(dphi_i, -|J| J^-1 (sigma .* xi))
+    (src/examples/homogenized_coefficients.jl:449-474)"""
+    xi = np.ascontiguousarray(xi, dtype=np.float64)
+    L.check(L.load().hmg_rhs_axi_grad(implicit.h, xi.ctypes.data_as(L.p_f64), b.h))
+
+
+def next_rhs(b: DeviceMatrix, x: DeviceMatrix, implicit: ImplicitFineGrid):
+    """next_rhs!: b = lam*|J|*M*x  (src/examples/homogenized_coefficients.jl:695-713)"""
+    L.check(L.load().hmg_next_rhs(implicit.h, x.h, b.h))
 
 
 def smoothing_steps(steps, implicit, ops, curr: LevelState, k: int):

@@ -56,8 +56,12 @@ struct DevBuf {
 
 struct LevelBufs {
     DevBuf<uint64_t> meta;
+    DevBuf<uint16_t> lpos, sweep_slot;
+    DevBuf<uint32_t> pos32, sweep32;
+    DevBuf<uint64_t> sweep_meta;
     DevBuf<double> ctab;
     DevBuf<int32_t> hier2slot, par_a, par_b, rptr, ridx;
+    DevBuf<double> dphi;
 };
 
 struct CutKind {
@@ -70,7 +74,18 @@ struct CutKind {
 
 }  // namespace
 
+struct ApplyTimer {
+    bool on = false;
+    int min_level = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t used = 0;
+    double bytes = 0.0;
+    int64_t launches = 0;
+};
+
 struct hmg_ctx {
+    ApplyTimer timer;
+    bool fuse_cg_default = true;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -92,6 +107,9 @@ struct hmg_grid {
     MeshDev md{};
     DevBuf<int32_t> d_cells, d_face_pairs, d_edge_ptr, d_edge_ent, d_node_ptr, d_node_ent, d_node_first;
     DevBuf<uint16_t> d_dmask, d_dupmask;
+    DevBuf<uint8_t> d_mult;
+    DevBuf<double> d_blockpart;
+    bool fuse_cg = true;
     DevBuf<double> d_coef;
     std::vector<double> sigma, coef;
     double lambda = 0.0;
@@ -179,6 +197,8 @@ void upload_mesh(hmg_grid *g)
     g->d_node_first.upload(M.node_first, s);
     g->d_dmask.upload(M.dmask, s);
     g->d_dupmask.upload(M.dupmask, s);
+    g->d_mult.upload(M.mult, s);
+    if (g->d_blockpart.n < (size_t)M.ncells * 2) g->d_blockpart.alloc((size_t)M.ncells * 2);
     MeshDev &d = g->md;
     d.dim = M.dim;
     d.ncells = M.ncells;
@@ -195,6 +215,8 @@ void upload_mesh(hmg_grid *g)
     d.node_first = g->d_node_first.p;
     d.dmask = g->d_dmask.p;
     d.dupmask = g->d_dupmask.p;
+    d.mult = g->d_mult.p;
+    d.blockpart = g->d_blockpart.p;
     d.coef = g->d_coef.p;
 }
 
@@ -210,6 +232,30 @@ void upload_operator(hmg_grid *g)
 
 void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);   // defined below
 
+// every operator apply goes through here: optional HIP-event bracketing for bench.py's roofline
+void apply(hmg_grid *g, const LevelDev &lv, double alpha, const double *x, const double *src, double *out, int mask)
+{
+    hmg_ctx *c = g->ctx;
+    ApplyTimer &t = c->timer;
+    const bool timed = t.on && lv.level >= t.min_level;
+    if (timed) {
+        if (t.used == t.pool.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            t.pool.emplace_back(a, b);
+        }
+        HIPCHK(hipEventRecord(t.pool[t.used].first, c->stream));
+    }
+    launch_apply(c->L, lv, g->md, alpha, g->lambda, x, src, out, mask);
+    if (timed) {
+        HIPCHK(hipEventRecord(t.pool[t.used].second, c->stream));
+        t.used += 1;
+        t.launches += 1;
+        t.bytes += 8.0 * (double)lv.nf * (double)g->md.ncells * (src ? 3.0 : 2.0);
+    }
+}
+
 void interface_sum(hmg_grid *g, const LevelDev &lv, double *x)
 {
     launch_interface_sum(g->ctx->L, lv, g->md, x);
@@ -224,19 +270,72 @@ void scalar_sum(hmg_grid *g, int slot, int count)
     }
 }
 
+// one fused CG pass: p = r (+ beta*p), Ap = constraint(A p), partial sums for p.Ap (and r.r)
+void apply_fused(hmg_grid *g, const LevelDev &lv, const double *r, const double *pold, double *p, double *Ap,
+                 int s_num, int s_den, int slot_pap, int slot_rr)
+{
+    hmg_ctx *c = g->ctx;
+    ApplyTimer &t = c->timer;
+    const bool timed = t.on && lv.level >= t.min_level;
+    if (timed) {
+        if (t.used == t.pool.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            t.pool.emplace_back(a, b);
+        }
+        HIPCHK(hipEventRecord(t.pool[t.used].first, c->stream));
+    }
+    ApplyArgs a{};
+    a.alpha = 1.0;
+    a.lambda = g->lambda;
+    a.x = r;
+    a.x2 = pold;
+    a.xout = p;
+    a.src = nullptr;
+    a.out = Ap;
+    a.s_num = s_num;
+    a.s_den = s_den;
+    a.flags = 1;
+    launch_apply_fused(c->L, lv, g->md, a, slot_pap, slot_rr);
+    if (timed) {
+        HIPCHK(hipEventRecord(t.pool[t.used].second, c->stream));
+        t.used += 1;
+        t.launches += 1;
+        t.bytes += 8.0 * (double)lv.nf * (double)g->md.ncells * (pold ? 4.0 : 3.0);
+    }
+}
+
 void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap)
 {
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
     const Launch &L = g->ctx->L;
     const int64_t n = vec_len(x);
-    launch_apply(L, lv, g->md, -1.0, g->lambda, x->d, b->d, r->d, 1);   // r = b - A x, constraint
+    apply(g, lv, -1.0, x->d, b->d, r->d, 1);                            // r = b - A x, constraint
     interface_sum(g, lv, r->d);
     int cur = S_RS, other = S_RS2;
+    if (g->fuse_cg && !g->exchange) {
+        // p-update and both reductions ride along with the operator apply (see k_apply<.., FUSED>)
+        for (int i = 0; i < steps; ++i) {
+            if (i == 0)
+                apply_fused(g, lv, r->d, nullptr, p->d, Ap->d, 0, 0, S_PAP, cur);   // p = r; rs = r.r
+            else
+                apply_fused(g, lv, r->d, p->d, p->d, Ap->d, cur, other, S_PAP, -1); // beta = rs'/rs
+            interface_sum(g, lv, Ap->d);
+            launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, i == 0 ? other : other);
+            std::swap(cur, other);
+        }
+        if (steps > 0)
+            launch_cg_pupdate(L, p->d, r->d, n, cur, other);            // the reference's last p-update
+        else
+            launch_copy_dot(L, p->d, r->d, n, cur);
+        return;
+    }
     launch_copy_dot(L, p->d, r->d, n, cur);                              // p = r; rs = r.r
     scalar_sum(g, cur, 1);
     for (int i = 0; i < steps; ++i) {
-        launch_apply(L, lv, g->md, 1.0, g->lambda, p->d, nullptr, Ap->d, 1);   // Ap = A p, constraint
+        apply(g, lv, 1.0, p->d, nullptr, Ap->d, 1);                            // Ap = A p, constraint
         interface_sum(g, lv, Ap->d);
         launch_dot(L, p->d, Ap->d, n, S_PAP);
         scalar_sum(g, S_PAP, 1);
@@ -335,7 +434,7 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     hmg_vec **nxt = st + 5 * (k - 2);
     const Launch &L = g->ctx->L;
     smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4]);
-    launch_apply(L, lev(g, k), g->md, -1.0, g->lambda, cur[0]->d, cur[1]->d, cur[2]->d, 1);   // local residual
+    apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                            // local residual
     launch_restrict(L, lev(g, k), lev(g, k - 1), g->md.ncells, cur[2]->d, nxt[1]->d);
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st);
@@ -415,8 +514,9 @@ int hmg_ctx_create(int device, void *stream, hmg_ctx **out)
     c->L.partials = c->partials.p;
     c->L.scal = c->scal.p;
     c->L.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->L.apply_variant = 1;
+    c->L.apply_variant = 0;
     c->L.apply_threads = 0;
+    c->L.apply_mass_only = 0;
     *out = c.release();
     HMG_END
 }
@@ -453,6 +553,15 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->coarse_maxit = (int)value;
     else if (n == "coarse_check")
         ctx->coarse_check = std::max<int>(1, (int)value);
+    else if (n == "fuse_cg")
+        ctx->fuse_cg_default = value != 0;
+    else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
+        ctx->timer.on = value > 0;
+        ctx->timer.min_level = (int)value;
+        ctx->timer.used = 0;
+        ctx->timer.bytes = 0.0;
+        ctx->timer.launches = 0;
+    }
     else
         throw std::runtime_error("unknown option: " + n);
     HMG_END
@@ -472,6 +581,23 @@ int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value)
 
 void *hmg_ctx_scalar_bank(hmg_ctx *ctx) { return ctx ? (void *)ctx->scal.p : nullptr; }
 
+int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, double *total_bytes)
+{
+    HMG_TRY
+    need(ctx && launches && total_ms && total_bytes, "null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    double ms = 0.0;
+    for (size_t i = 0; i < ctx->timer.used; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, ctx->timer.pool[i].first, ctx->timer.pool[i].second));
+        ms += t;
+    }
+    *launches = ctx->timer.launches;
+    *total_ms = ms;
+    *total_bytes = ctx->timer.bytes;
+    HMG_END
+}
+
 int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
                     const int64_t *cells, hmg_grid **out)
 {
@@ -480,6 +606,7 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
     if (ctx) HIPCHK(hipSetDevice(ctx->device));
     std::unique_ptr<hmg_grid> g(new hmg_grid);
     g->ctx = ctx;
+    g->fuse_cg = ctx ? ctx->fuse_cg_default : true;
     g->dim = dim;
     g->nlevels = nlevels;
     g->lt = build_level_tables(dim, nlevels);
@@ -492,12 +619,43 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
         LevelBufs &B = *g->lb.back();
         if (ctx) {
             B.meta.upload(T.meta, s);
+            {
+                std::vector<uint16_t> lp(T.meta.size());
+                for (size_t q = 0; q < lp.size(); ++q) lp[q] = (uint16_t)(T.meta[q] & 0xffffu);
+                B.lpos.upload(lp, s);
+            }
+            {
+                // compact addressing word: L | j<<16 | k<<22 | cls<<28  (len, A, B follow from j, k, m)
+                auto pack32 = [&](uint64_t mt, int cls) {
+                    uint32_t Lx = (uint32_t)(mt & 0xffffu), len = (uint32_t)((mt >> 16) & 0xffu);
+                    uint32_t A = (uint32_t)((mt >> 32) & 0xffffu);
+                    // recover j, k: len = m+1-j-k ; A = T_k - j (3D) ; 2D: k = 0
+                    uint32_t k = 0, j = 0;
+                    if (T.dim == 3) {
+                        for (k = 0; k <= (uint32_t)T.m; ++k) {
+                            uint32_t n = T.m - k, Tk = (n + 1) * (n + 2) / 2;
+                            j = T.m + 1 - k - len;
+                            if (Tk - j == A) break;
+                        }
+                    } else
+                        j = T.m + 1 - len;
+                    return Lx | (j << 16) | (k << 22) | ((uint32_t)cls << 28);
+                };
+                std::vector<uint32_t> p32(T.meta.size()), s32(T.sweep_meta.size());
+                for (size_t q = 0; q < p32.size(); ++q) p32[q] = pack32(T.meta[q], T.slot_cls[q]);
+                for (size_t q = 0; q < s32.size(); ++q) s32[q] = pack32(T.sweep_meta[q], 0);
+                B.pos32.upload(p32, s);
+                B.sweep32.upload(s32, s);
+            }
+            B.sweep_meta.upload(T.sweep_meta, s);
+            B.sweep_slot.upload(T.sweep_slot, s);
             B.ctab.upload(T.ctab, s);
             B.hier2slot.upload(T.hier2slot, s);
             B.par_a.upload(T.par_a, s);
             B.par_b.upload(T.par_b, s);
             B.rptr.upload(T.rptr, s);
             B.ridx.upload(T.ridx, s);
+            B.dphi.upload(T.dphi, s);
         }
         LevelDev &D = g->ld[l];
         D.dim = T.dim;
@@ -521,12 +679,19 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
         D.lds_g1 = T.lds_g1;
         D.nf_coarse = l > 0 ? g->lt[l - 1].nf : 0;
         D.meta = B.meta.p;
+        D.lpos = B.lpos.p;
+        D.sweep_meta = B.sweep_meta.p;
+        D.sweep_slot = B.sweep_slot.p;
+        D.pos32 = B.pos32.p;
+        D.sweep32 = B.sweep32.p;
+        D.nsweep = (int)T.sweep_meta.size();
         D.ctab = B.ctab.p;
         D.hier2slot = B.hier2slot.p;
         D.par_a = B.par_a.p;
         D.par_b = B.par_b.p;
         D.rptr = B.rptr.p;
         D.ridx = B.ridx.p;
+        D.dphi = B.dphi.p;
     }
     upload_mesh(g.get());
     *out = g.release();
@@ -848,7 +1013,19 @@ int hmg_apply(hmg_grid *g, int level, double alpha, hmg_vec *x, hmg_vec *y)
     check_vec(g, level, x, "x");
     check_vec(g, level, y, "y");
     need(x->d != y->d, "x and y must not alias");
-    launch_apply(g->ctx->L, lev(g, level), g->md, alpha, g->lambda, x->d, y->d, y->d, 0);
+    apply(g, lev(g, level), alpha, x->d, y->d, y->d, 0);
+    HMG_END
+}
+
+int hmg_apply_ex(hmg_grid *g, int level, double alpha, hmg_vec *x, hmg_vec *src, hmg_vec *out, int constrain)
+{
+    HMG_TRY
+    need(g && g->has_op, "operator not set");
+    check_vec(g, level, x, "x");
+    check_vec(g, level, out, "out");
+    if (src) check_vec(g, level, src, "src");
+    need(x->d != out->d, "x and out must not alias");
+    apply(g, lev(g, level), alpha, x->d, src ? src->d : nullptr, out->d, constrain ? 1 : 0);
     HMG_END
 }
 
@@ -860,7 +1037,7 @@ int hmg_residual(hmg_grid *g, int level, hmg_vec *x, hmg_vec *b, hmg_vec *r)
     check_vec(g, level, b, "b");
     check_vec(g, level, r, "r");
     need(x->d != r->d, "x and r must not alias");
-    launch_apply(g->ctx->L, lev(g, level), g->md, -1.0, g->lambda, x->d, b->d, r->d, 1);
+    apply(g, lev(g, level), -1.0, x->d, b->d, r->d, 1);
     HMG_END
 }
 
@@ -931,6 +1108,51 @@ int hmg_scatter_base(hmg_grid *g, const double *host_u, hmg_vec *v1)
     HIPCHK(hipMemcpyAsync(u.p, host_u, sizeof(double) * g->md.nnodes, hipMemcpyHostToDevice, g->ctx->stream));
     launch_scatter_base(g->ctx->L, g->md, lev(g, 1).ld, u.p, v1->d);
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    HMG_END
+}
+
+// ---- driver right-hand sides -------------------------------------------------------
+int hmg_rhs_axi_grad(hmg_grid *g, const double *xi, hmg_vec *b)
+{
+    HMG_TRY
+    need(g && g->has_op && xi && b, "null argument or operator not set");
+    check_vec(g, b->level, b, "b");
+    const MeshTables &M = g->cur();
+    const int dim = g->dim;
+    // P = -detJ * (Jinv' * (sigma .* xi))   (ref: ...homogenized_coefficients.jl:468)
+    std::vector<double> pv((size_t)M.ncells * 3, 0.0);
+    for (int64_t c = 0; c < M.ncells; ++c) {
+        const double *Ji = &M.jinv[(size_t)c * dim * dim];
+        const double *sg = &g->sigma[(size_t)c * dim];
+        for (int a = 0; a < dim; ++a) {
+            double s = 0.0;
+            for (int k = 0; k < dim; ++k) s += Ji[k + dim * a] * (sg[k] * xi[k]);
+            pv[(size_t)c * 3 + a] = -M.detj[c] * s;
+        }
+    }
+    DevBuf<double> d;
+    d.upload(pv, g->ctx->stream);
+    launch_rhs_dphi(g->ctx->L, lev(g, b->level), M.ncells, d.p, b->d);
+    HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    HMG_END
+}
+
+int hmg_next_rhs(hmg_grid *g, hmg_vec *x, hmg_vec *b)
+{
+    HMG_TRY
+    need(g && g->has_op && x && b, "null argument or operator not set");
+    check_vec(g, x->level, b, "b");
+    check_vec(g, x->level, x, "x");
+    need(x->d != b->d, "x and b must not alias");
+    // b = lambda*|J|*M*x  (ref: ...homogenized_coefficients.jl:695-713)
+    g->ctx->L.apply_mass_only = 1;
+    try {
+        launch_apply(g->ctx->L, lev(g, x->level), g->md, 1.0, g->lambda, x->d, nullptr, b->d, 0);
+    } catch (...) {
+        g->ctx->L.apply_mass_only = 0;
+        throw;
+    }
+    g->ctx->L.apply_mass_only = 0;
     HMG_END
 }
 

@@ -16,10 +16,17 @@ struct LevelDev {
     int lds_g0, lds_g1;
     int nf_coarse;                 // nf of level-1 (0 on level 1)
     const uint64_t *meta;          // [nf]
+    const uint16_t *lpos;          // [nf] LDS lattice index of every storage slot
+    const uint64_t *sweep_meta;    // [nsweep] interior sweep (lattice order, idle lanes on surface ends)
+    const uint16_t *sweep_slot;    // [nsweep] storage slot or 0xffff
+    int nsweep;
+    const uint32_t *pos32;         // [nf]     L | j<<16 | k<<22 | cls<<28
+    const uint32_t *sweep32;       // [nsweep] same packing, cls = 0
     const double *ctab;            // [ncls*ndir*nterm]
     const int32_t *hier2slot;      // [nf]
     const int32_t *par_a, *par_b;  // [nf]     (level > 1)
     const int32_t *rptr, *ridx;    // [nf_coarse+1], [..] (level > 1)
+    const double *dphi;            // [3*nf]
 };
 
 struct MeshDev {
@@ -35,6 +42,22 @@ struct MeshDev {
     const int32_t *node_first;   // nnodes
     const uint16_t *dmask, *dupmask;
     const double *coef;          // 8 per cell
+    const uint8_t *mult;         // 16 per cell: number of copies of each entity (bit order of the masks)
+    double *blockpart;           // 2 per cell: scratch for the fused apply's block sums
+};
+
+struct ApplyArgs {
+    double alpha, lambda;
+    const double *x;       // input column; with x2: xin = x + beta * x2, beta = scal[s_num] / scal[s_den]
+    const double *x2;
+    double *xout;          // optional: xin written back (p-update / p = r)
+    const double *src;     // optional: out = src + alpha * A * xin
+    double *out;
+    const double *scal;
+    int s_num, s_den;
+    double *blockpart;
+    const uint8_t *mult;
+    int flags;             // bit 0: Dirichlet constraint on out; bit 1: mass term only
 };
 
 struct CoarseDev {
@@ -54,12 +77,17 @@ struct Launch {
     int num_cu;
     int apply_variant;    // 0 generic, 1 persistent register-meta
     int apply_threads;    // 0 = auto
+    int apply_mass_only;  // 1: only the mass term (next_rhs!), set around a single launch
 };
 
 // out = (src ? src : 0) + alpha * A x, then (use_mask) zero Dirichlet DOFs.  src may alias out.
 void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
                   const double *x, const double *src, double *out, int use_mask);
 size_t apply_lds_bytes(const LevelDev &lv);
+// Fused CG pass: see k_apply<.., FUSED>.  scal[slot_pap] = sum mult*xin*out, scal[slot_rr] = sum xin*xin
+// (slot_rr < 0: not wanted).  a.scal / a.mult / a.blockpart are filled in by the launcher.
+void launch_apply_fused(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a, int slot_pap,
+                        int slot_rr);
 
 void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x);
 void launch_mask(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which /*0 dmask,1 dupmask*/);
@@ -101,6 +129,9 @@ void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
                           const double *q);   // alpha=C0/C1; S_C3 = r.z (new); S_TMP = r.r
 void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z);   // beta=C3/C0; C0=C3
+
+// b[slot, cell] = dot(dphi[slot], pvec[cell])   (rhs_a xi grad v)
+void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const double *pvec, double *b);
 
 // multi-GPU cut exchange: unpack = 0 packs buf[gid] <- x (first local copy), 1 writes x <- buf[gid]
 void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nentries, const int64_t *gid,

@@ -35,10 +35,19 @@ struct LevelTables {
     // packed per-slot stencil addressing word (see pack_meta)
     std::vector<uint64_t> meta;
     int lds_g0 = 0, lds_g1 = 0;   // LDS guard entries in front of / behind the lattice image
+    // cell-interior sweep in LDS lattice order: every interior row with its two end (surface)
+    // positions kept as idle lanes so that a half-wave reads contiguous LDS words.
+    // sweep_meta: L | len<<16 | A<<32 | B<<48 ; sweep_slot: storage slot or 0xffff (idle)
+    std::vector<uint64_t> sweep_meta;
+    std::vector<uint16_t> sweep_slot;
 
     // stencil in class form: ctab[(cls*ndir + dir)*nterm + term]
     int ncls = 0, ndir = 0, nterm = 0;
     std::vector<double> ctab;
+
+    // dphi[3*slot + a] = int d phi_slot / d x_a over the refined reference simplex
+    // (ref: src/examples/homogenized_coefficients.jl:407-442, partial_derivatives_functionals)
+    std::vector<double> dphi;
 
     // transfer operators between level-1 (coarse) and this level (fine); empty on level 1.
     // prolongation: fine slot <- 0.5*coarse[pa] + 0.5*coarse[pb] (pa == pb: identity row);
@@ -81,6 +90,8 @@ struct MeshTables {
     std::vector<int32_t> node_first;
     // per cell: Dirichlet entity bitmask and "not the first copy" bitmask; bit = cls-1
     std::vector<uint16_t> dmask, dupmask;
+    // per cell, 16 bytes: number of copies of each of the cell's entities (same bit order as the masks)
+    std::vector<uint8_t> mult;
     // boundary (Dirichlet) base nodes flag
     std::vector<uint8_t> node_on_boundary;
 

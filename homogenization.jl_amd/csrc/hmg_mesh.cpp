@@ -130,6 +130,11 @@ void build_from_cells0(MeshTables &M)
 
     M.dmask.assign(M.ncells, 0);
     M.dupmask.assign(M.ncells, 0);
+    M.mult.assign((size_t)M.ncells * 16, 1);
+    auto set_mult = [&](int32_t cell, int bit, size_t n) {
+        if (n > 255) throw std::runtime_error("base mesh: an entity is shared by more than 255 cells");
+        M.mult[(size_t)cell * 16 + bit] = (uint8_t)n;
+    };
     M.node_on_boundary.assign(M.nnodes, 0);
     M.face_pairs.clear();
     M.edge_ptr.assign(1, 0);
@@ -155,6 +160,8 @@ void build_from_cells0(MeshTables &M)
                 M.face_pairs.push_back(faces[i + 1].cell);
                 M.face_pairs.push_back(faces[i].lid | (faces[i + 1].lid << 4));
                 M.dupmask[faces[i + 1].cell] |= bit_face(faces[i + 1].lid);
+                set_mult(faces[i].cell, faces[i].lid, 2);
+                set_mult(faces[i + 1].cell, faces[i + 1].lid, 2);
             } else
                 throw std::runtime_error("base mesh: a face is shared by more than two cells");
         });
@@ -175,6 +182,7 @@ void build_from_cells0(MeshTables &M)
             for (size_t q = i; q < j; ++q) {
                 if (bnd) M.dmask[edges[q].cell] |= bit_edge(edges[q].lid);
                 if (q > i) M.dupmask[edges[q].cell] |= bit_edge(edges[q].lid);
+                set_mult(edges[q].cell, nface + edges[q].lid, j - i);
             }
             if (j - i >= 2) {   // singletons removed (src/interface.jl:99)
                 for (size_t q = i; q < j; ++q) M.edge_ent.push_back(edges[q].cell * 8 + edges[q].lid);
@@ -191,6 +199,7 @@ void build_from_cells0(MeshTables &M)
             for (size_t q = i; q < j; ++q) {
                 if (bnd) M.dmask[nodes[q].cell] |= bit_node(nodes[q].lid);
                 if (q > i) M.dupmask[nodes[q].cell] |= bit_node(nodes[q].lid);
+                set_mult(nodes[q].cell, nface + nedge + nodes[q].lid, j - i);
             }
             if (j - i >= 2) {
                 for (size_t q = i; q < j; ++q) M.node_ent.push_back(nodes[q].cell * 8 + nodes[q].lid);

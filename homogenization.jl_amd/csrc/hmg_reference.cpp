@@ -187,60 +187,76 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
         T.slot2hier.assign(nf, -1);
         T.slot_cls.assign(nf, 0);
         T.slot_ijk.assign((size_t)nf * 3, 0);
-        std::vector<int> fill_edge(nedge, 0), fill_face(std::max(nface, 1), 0);
+        // Within an edge / face the DOFs are stored in lattice order (k, then j, then i ascending).
+        // That order is canonical across the cells sharing the entity: a cell's node tuple is
+        // ascending in the global numbering, so the barycentric coordinates of a fine node with
+        // respect to the entity's local vertices (taken in local order) are the same in every
+        // adjacent cell, and (k, j, i) lexicographic order equals lexicographic order of those
+        // barycentric coordinates on each of the 4 faces / 6 edges of the reference simplex.
+        // (The reference lists entity nodes by ascending node id, src/multilevel_reference.jl:125-203;
+        // any order shared by all copies gives the same interface sums.)
+        std::vector<std::vector<int32_t>> edge_nodes(nedge), face_nodes(std::max(nface, 1));
         std::vector<int32_t> interior;
         auto cls_face = [&](int f) { return 1 + f; };
         auto cls_edge = [&](int e) { return 1 + nface + e; };
         auto cls_corner = [&](int c) { return 1 + nface + nedge + c; };
         for (int h = 0; h < nf; ++h) {
             const int i = hc[h][0], j = hc[h][1], k = hc[h][2];
-            int slot, cls;
             if (h < ncorner) {
-                slot = h;
-                cls = cls_corner(h);
+                T.hier2slot[h] = h;
+                T.slot2hier[h] = h;
+                T.slot_cls[h] = (uint8_t)cls_corner(h);
             } else if (dim == 3) {
                 bool on[4] = {k == 0, j == 0, i == 0, i + j + k == m};
                 int cnt = on[0] + on[1] + on[2] + on[3];
-                if (cnt == 0) {
+                if (cnt == 0)
                     interior.push_back(h);
-                    continue;
-                } else if (cnt == 1) {
-                    int f = on[0] ? 0 : on[1] ? 1 : on[2] ? 2 : 3;
-                    slot = T.off_face + f * T.nfi + fill_face[f]++;
-                    cls = cls_face(f);
-                } else if (cnt == 2) {
+                else if (cnt == 1)
+                    face_nodes[on[0] ? 0 : on[1] ? 1 : on[2] ? 2 : 3].push_back(h);
+                else if (cnt == 2)
                     // edges (1,2)=f0&f1 (1,3)=f0&f2 (1,4)=f1&f2 (2,3)=f0&f3 (2,4)=f1&f3 (3,4)=f2&f3
-                    int e = on[0] && on[1] ? 0 : on[0] && on[2] ? 1 : on[1] && on[2] ? 2
-                          : on[0] && on[3] ? 3 : on[1] && on[3] ? 4 : 5;
-                    slot = T.off_edge + e * T.nei + fill_edge[e]++;
-                    cls = cls_edge(e);
-                } else {
+                    edge_nodes[on[0] && on[1] ? 0 : on[0] && on[2] ? 1 : on[1] && on[2] ? 2
+                               : on[0] && on[3] ? 3 : on[1] && on[3] ? 4 : 5].push_back(h);
+                else
                     throw std::runtime_error("reference lattice: non-corner node on 3 faces");
-                }
             } else {
                 bool on[3] = {j == 0, i == 0, i + j == m};
                 int cnt = on[0] + on[1] + on[2];
-                if (cnt == 0) {
+                if (cnt == 0)
                     interior.push_back(h);
-                    continue;
-                } else if (cnt == 1) {
-                    int e = on[0] ? 0 : on[1] ? 1 : 2;
-                    slot = T.off_edge + e * T.nei + fill_edge[e]++;
-                    cls = cls_edge(e);
-                } else {
+                else if (cnt == 1)
+                    edge_nodes[on[0] ? 0 : on[1] ? 1 : 2].push_back(h);
+                else
                     throw std::runtime_error("reference lattice: non-corner node on 2 edges");
-                }
             }
-            T.hier2slot[h] = slot;
-            T.slot2hier[slot] = h;
-            T.slot_cls[slot] = (uint8_t)cls;
         }
-        // interior: lattice order (k, j, i ascending)
-        std::sort(interior.begin(), interior.end(), [&](int32_t a, int32_t b) {
+        auto lattice_less = [&](int32_t a, int32_t b) {
             if (hc[a][2] != hc[b][2]) return hc[a][2] < hc[b][2];
             if (hc[a][1] != hc[b][1]) return hc[a][1] < hc[b][1];
             return hc[a][0] < hc[b][0];
-        });
+        };
+        for (int e = 0; e < nedge; ++e) {
+            if ((int)edge_nodes[e].size() != T.nei) throw std::runtime_error("reference lattice: edge count");
+            std::sort(edge_nodes[e].begin(), edge_nodes[e].end(), lattice_less);
+            for (int q = 0; q < T.nei; ++q) {
+                int h = edge_nodes[e][q], slot = T.off_edge + e * T.nei + q;
+                T.hier2slot[h] = slot;
+                T.slot2hier[slot] = h;
+                T.slot_cls[slot] = (uint8_t)cls_edge(e);
+            }
+        }
+        for (int f = 0; f < nface; ++f) {
+            if ((int)face_nodes[f].size() != T.nfi) throw std::runtime_error("reference lattice: face count");
+            std::sort(face_nodes[f].begin(), face_nodes[f].end(), lattice_less);
+            for (int q = 0; q < T.nfi; ++q) {
+                int h = face_nodes[f][q], slot = T.off_face + f * T.nfi + q;
+                T.hier2slot[h] = slot;
+                T.slot2hier[slot] = h;
+                T.slot_cls[slot] = (uint8_t)cls_face(f);
+            }
+        }
+        // interior: lattice order (k, j, i ascending)
+        std::sort(interior.begin(), interior.end(), lattice_less);
         if ((int)interior.size() != T.nint) throw std::runtime_error("reference lattice: interior count");
         for (int q = 0; q < T.nint; ++q) {
             int h = interior[q], slot = T.off_int + q;
@@ -248,10 +264,6 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
             T.slot2hier[slot] = h;
             T.slot_cls[slot] = 0;
         }
-        for (int e = 0; e < nedge; ++e)
-            if (fill_edge[e] != T.nei) throw std::runtime_error("reference lattice: edge count");
-        for (int f = 0; f < nface; ++f)
-            if (fill_face[f] != T.nfi) throw std::runtime_error("reference lattice: face count");
         for (int s = 0; s < nf; ++s) {
             int h = T.slot2hier[s];
             T.slot_ijk[3 * s + 0] = hc[h][0];
@@ -296,11 +308,37 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
         T.lds_g0 = -amin;
         T.lds_g1 = amax - (nf - 1);
 
+        // interior sweep: rows (j,k) that contain cell-interior nodes, all positions i = 0..len-1
+        T.sweep_meta.clear();
+        T.sweep_slot.clear();
+        if (T.nint > 0) {
+            std::vector<int32_t> slot_of_L(nf, -1);
+            for (int s2 = 0; s2 < nf; ++s2) slot_of_L[(int)(T.meta[s2] & 0xffffu)] = s2;
+            const int kmax = dim == 3 ? m : 0;
+            for (int k = (dim == 3 ? 1 : 0); k <= kmax; ++k)
+                for (int j = 1; j <= m - k; ++j) {
+                    int len = m + 1 - j - k;
+                    if (len < 3) continue;   // no interior node in this row
+                    for (int i = 0; i < len; ++i) {
+                        int L = lin(i, j, k);
+                        int sl = slot_of_L[L];
+                        bool active = T.slot_cls[sl] == 0;
+                        uint64_t mt = T.meta[sl] & ~((uint64_t)0xff << 24);
+                        T.sweep_meta.push_back(mt);
+                        T.sweep_slot.push_back(active ? (uint16_t)sl : (uint16_t)0xffff);
+                    }
+                }
+            size_t nact = 0;
+            for (uint16_t v : T.sweep_slot) nact += v != 0xffff;
+            if ((int)nact != T.nint) throw std::runtime_error("reference lattice: interior sweep does not cover the interior");
+        }
+
         // ---- stencil rows by summing the sub-simplices around every node -------------------
         T.ncls = 1 + nface + nedge + ncorner;
         T.ndir = ndir;
         T.nterm = nterm;
         std::vector<double> rows((size_t)nf * ndir * nterm, 0.0);
+        T.dphi.assign((size_t)nf * 3, 0.0);
         std::vector<int32_t> slot_at((size_t)(m + 1) * (m + 1) * (dim == 3 ? m + 1 : 1), -1);
         for (int s = 0; s < nf; ++s)
             slot_at[lat.idx(T.slot_ijk[3 * s], T.slot_ijk[3 * s + 1], T.slot_ijk[3 * s + 2])] = s;
@@ -332,6 +370,8 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
                         simplex_gradients(dim, m, V, g, vol);
                         int sl[4];
                         for (int v = 0; v <= dim; ++v) sl[v] = slot_at[lat.idx(V[v][0], V[v][1], V[v][2])];
+                        for (int u = 0; u <= dim; ++u)
+                            for (int a = 0; a < dim; ++a) T.dphi[(size_t)sl[u] * 3 + a] += vol * g[a][u];
                         for (int u = 0; u <= dim; ++u)
                             for (int v = 0; v <= dim; ++v) {
                                 int d = dir_index(dim, V[v][0] - V[u][0], V[v][1] - V[u][1], V[v][2] - V[u][2]);

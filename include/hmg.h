@@ -43,6 +43,9 @@ int hmg_ctx_sync(hmg_ctx *ctx);
  * "coarse_check" ; "coarse_rtol" via hmg_ctx_set_option_f64 */
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
 int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value);
+/* HIP-event timing of the operator-apply launches of levels >= the value given to option "time_apply"
+ * (0 switches it off; setting it resets the counters).  Synchronises the stream. */
+int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, double *total_bytes);
 
 /* ---- grid: ImplicitFineGrid(base, levels)  (src/implicit_fine_grid.jl:13-18) ------------------ */
 /* Also derives ZeroDirichletConstraint(list_boundary_nodes_edges_faces(base)...)
@@ -85,6 +88,9 @@ int hmg_vec_norm_unique(hmg_vec *r, double *out);        /* norm after zero_out_
 /* ---- hot-path primitives -------------------------------------------------------------------- */
 /* mul!(alpha, base, A::L2PlusDivAGrad, x, y): y += alpha*A*x   (src/apply_local_operators.jl:85-133) */
 int hmg_apply(hmg_grid *grid, int level, double alpha, hmg_vec *x, hmg_vec *y);
+/* general form behind mul!/local_residual!/the smoother's Ap = A*p: out = (src ? src : 0) + alpha*A*x, then
+ * (constrain != 0) apply_constraint!(out).  src may be NULL or alias out. */
+int hmg_apply_ex(hmg_grid *grid, int level, double alpha, hmg_vec *x, hmg_vec *src, hmg_vec *out, int constrain);
 /* local_residual!: r = b - A*x, then constraint            (src/apply_local_operators.jl:18-27) */
 int hmg_residual(hmg_grid *grid, int level, hmg_vec *x, hmg_vec *b, hmg_vec *r);
 /* apply_constraint!                                          (src/implicit_fine_grid.jl:94-139) */
@@ -100,6 +106,12 @@ int hmg_prolong_add(hmg_grid *grid, int level_fine, hmg_vec *x_coarse, hmg_vec *
 /* copy_to_base! / distribute!                                (src/implicit_fine_grid.jl:148-202) */
 int hmg_gather_base(hmg_grid *grid, hmg_vec *v1, double *host_u /* nnodes */);
 int hmg_scatter_base(hmg_grid *grid, const double *host_u, hmg_vec *v1);
+
+/* ---- driver right-hand sides (run once per outer step) --------------------------------- */
+/* rhs_a xi grad v!(b, dphis, implicit, sigmas, xi)   (src/examples/homogenized_coefficients.jl:449-474) */
+int hmg_rhs_axi_grad(hmg_grid *grid, const double *xi /* dim */, hmg_vec *b);
+/* next_rhs!(b, x, implicit, ops): b = lambda*|J|*M*x  (src/examples/homogenized_coefficients.jl:695-713) */
+int hmg_next_rhs(hmg_grid *grid, hmg_vec *x, hmg_vec *b);
 
 /* ---- fused fast path ------------------------------------------------------------------------ */
 /* smoothing_steps!(steps, implicit, ops, curr, k)            (src/multigrid.jl:46-71) */

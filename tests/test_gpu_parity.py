@@ -279,3 +279,22 @@ def test_errors_are_reported_not_thrown(case3):
         hmg.mul(1.0, c.g, c.A, a, b)          # level mismatch
     with pytest.raises(hmg._lib.HmgError):
         hmg.mul(1.0, c.g, c.A, b, b)          # aliasing
+
+
+def test_driver_right_hand_sides(case3):
+    """rhs_a xi grad v! and next_rhs! -- ref: src/examples/homogenized_coefficients.jl:449-474, 695-713"""
+    c = case3
+    O = c.O
+    lev = c.levels
+    xi = np.ones(3) / np.sqrt(3.0)
+    dphis = O.partial_derivatives_functionals(c.impl.reference.levels[-1])
+    want = np.zeros((c.impl.nf(lev), c.mesh.nelements()), order="F")
+    O.rhs_axi_grad_v(want, dphis, c.impl, c.sig, xi)
+    b = hmg.DeviceMatrix(c.g, lev)
+    hmg.rhs_axi_grad_v(b, c.g, xi)
+    assert relerr(b.to_host(), want) <= 1e-12
+    x = c.rand(lev)
+    want2 = np.zeros_like(x, order="F")
+    O.next_rhs(want2, x, c.impl, O.mass_matrix(c.impl.reference.levels[-1]), c.lam)
+    hmg.next_rhs(b, c.dev(lev, x), c.g)
+    assert relerr(b.to_host(), want2) <= 1e-12

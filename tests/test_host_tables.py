@@ -44,15 +44,51 @@ def test_numbering_and_entities(oracle, dim, levels):
         want = np.round(ref.levels[lev - 1].nodes * m).astype(int)
         np.testing.assert_array_equal(ijk[h2s][:, :dim], want)
         nb = ref.numbering[lev - 1]
-        # entity-major storage: every entity is one contiguous run in the reference's list order
+        # entity-major storage: every entity of the reference's numbering is one contiguous run
+        # (inside a run the library uses lattice order, see test_entity_order_is_canonical)
         np.testing.assert_array_equal(h2s[nb.nodes], np.arange(dim + 1))
         for e, lst in enumerate(nb.edges_interior):
-            np.testing.assert_array_equal(h2s[lst], off_edge + e * nei + np.arange(len(lst)))
+            np.testing.assert_array_equal(np.sort(h2s[lst]), off_edge + e * nei + np.arange(len(lst)))
             assert len(lst) == nei
         if dim == 3:
             for f, lst in enumerate(nb.faces_interior):
-                np.testing.assert_array_equal(h2s[lst], off_face + f * nfi + np.arange(len(lst)))
+                np.testing.assert_array_equal(np.sort(h2s[lst]), off_face + f * nfi + np.arange(len(lst)))
                 assert len(lst) == nfi
+
+
+@pytest.mark.parametrize("dim,levels,times", [(3, 5, 2), (2, 6, 2)])
+def test_entity_order_is_canonical(oracle, dim, levels, times):
+    """The k-th stored DOF of a shared face / edge is the same physical point in every adjacent cell
+    (the property test/implicit_grid.jl:8-92 checks for the reference's ascending-id lists), here for
+    the library's lattice order, on a refined 5-tet cube / a perturbed triangle mesh."""
+    O = oracle
+    if dim == 3:
+        nodes = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 1)], float)
+        els = np.array([(1, 2, 3, 5), (2, 3, 4, 8), (3, 5, 7, 8), (2, 5, 6, 8), (2, 3, 5, 8)]) - 1
+        m = O.refine_uniformly(O.Mesh(nodes, els), times=times)
+        m.elements = O.sort_element_nodes(m.elements)
+    else:
+        m = small_mesh(O, 2, 4, perturb=0.3, seed=9)
+    g = host_grid(m, levels)
+    impl = O.ImplicitFineGrid.create(m, levels)
+    for lev in range(2, levels + 1):
+        lay = g.table_i32("layout", lev)
+        nei, nfi, off_edge, off_face = lay[5], lay[6], lay[8], lay[9]
+        h2s = g.table_i32("hier2slot", lev)
+        s2h = np.argsort(h2s)
+        full = impl.construct_full_grid(lev)                              # (Ne, Nf(hier), dim)
+        if dim == 3 and nfi:
+            fp = g.table_i32("face_pairs").reshape(-1, 3)
+            for ca, cb, lf in fp:
+                a = full[ca, s2h[off_face + (lf & 15) * nfi + np.arange(nfi)]]
+                b = full[cb, s2h[off_face + (lf >> 4) * nfi + np.arange(nfi)]]
+                np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+        if nei:
+            ptr, ent = g.table_i32("edge_ptr"), g.table_i32("edge_ent")
+            for e in range(len(ptr) - 1):
+                pts = [full[v >> 3, s2h[off_edge + (v & 7) * nei + np.arange(nei)]] for v in ent[ptr[e]:ptr[e + 1]]]
+                for p in pts[1:]:
+                    np.testing.assert_allclose(p, pts[0], rtol=0, atol=1e-12)
 
 
 @pytest.mark.parametrize("dim,levels", [(3, 5), (2, 6)])
@@ -219,3 +255,30 @@ def test_no_cpu_compute_path():
     import torch
     if not torch.cuda.is_available():
         assert rc != 0 and b"no CPU fallback" in lib.hmg_last_error()
+
+
+@pytest.mark.parametrize("dim,n", [(3, 5), (2, 7)])
+def test_driver_mesh_matches_reference_generator(oracle, dim, n):
+    """Product host mesh synthesis == literal restatement of hypercube + order_nodes_and_elements_by_magnitude
+    (ref: src/tet/generate_grid.jl, src/examples/homogenized_coefficients.jl:21-28, :494-503)."""
+    from homogenization_jl_amd import driver
+    O = oracle
+    tag = hmg.Tet64 if dim == 3 else hmg.Tri64
+    origin = (-n / 2.0,) * dim
+    a = driver.hypercube(tag, n, origin=origin)
+    b = O.hypercube(dim, n, origin=origin)
+    np.testing.assert_array_equal(a.nodes, b.nodes)
+    np.testing.assert_array_equal(a.elements - 1, b.elements)
+    a2 = driver.order_nodes_and_elements_by_magnitude(a)
+    b2 = O.order_nodes_and_elements_by_magnitude(b)
+    np.testing.assert_array_equal(a2.nodes, b2.nodes)
+    np.testing.assert_array_equal(a2.elements - 1, b2.elements)
+    grid = driver.generate_conductivity(dim, n, 3)
+    off = tuple(1.0 - o for o in origin)
+    np.testing.assert_array_equal(driver.conductivity_per_element(a2, grid, off),
+                                  O.conductivity_per_element(b2, grid, off))
+    assert driver.find_elements_in_radius(a2, 1) == O.find_elements_in_radius(b2, 1)
+    assert driver.find_nodes_in_radius(a2, 1) == O.find_nodes_in_radius(b2, 1)
+    for lam, nn in ((1.0, 2), (0.5, 3), (0.25, 1)):
+        assert driver.compute_boundary_layer(lam, nn) == O.compute_boundary_layer(lam, nn)
+        assert driver.compute_box_radius(2, nn) == O.compute_box_radius(2, nn)
