@@ -171,8 +171,8 @@ __device__ __forceinline__ void decode32(uint32_t w, int m, int &L, int &len, in
 //   load phase   xin = x + beta*x2 (p = r + beta*p), written back to xout; block sum of xin*xin
 //   epilogue     block sum of mult*xin*out  == this cell's share of dot(p, interface_sum(A p)), because
 //                p is identical in all copies of a shared DOF (src/multigrid.jl:54-68)
-template <int DIM, int NT, bool FUSED>
-__global__ void __launch_bounds__(NT)
+template <int DIM, int NT, int SPT, bool FUSED>
+__global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 1)   // 2 x 1024 threads per CU need <= 64 VGPRs
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
     constexpr int NDIR = DIM == 3 ? 15 : 7;
@@ -197,21 +197,45 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
     const double *xc = a.x + cell * lv.ld;
     double rr = 0.0, pap = 0.0;
-    if (FUSED) {
-        const double *x2c = a.x2 ? a.x2 + cell * lv.ld : nullptr;
-        double *xoc = a.xout ? a.xout + cell * lv.ld : nullptr;
+    {
+        // Load phase in two passes -- all loads first, then stores / LDS writes -- so that the store to
+        // xout (which may be the same array as x2) never sits between two loads of the same wave.
+        const double *x2c = FUSED && a.x2 ? a.x2 + cell * lv.ld : nullptr;
+        double *xoc = FUSED && a.xout ? a.xout + cell * lv.ld : nullptr;
         const double beta = x2c ? a.scal[a.s_num] / a.scal[a.s_den] : 0.0;
-#pragma unroll 4
-        for (int t = tid; t < nf; t += NT) {
-            double xv = xc[t];
-            if (x2c) xv = xv + beta * x2c[t];
-            if (xoc) xoc[t] = xv;
-            rr += xv * xv;
-            xs[lv.lpos[t]] = xv;
+        double xv[SPT], x2v[SPT];
+        int lp[SPT];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int t = tid + q * NT;
+            if (t < nf) {
+                xv[q] = xc[t];
+                x2v[q] = x2c ? x2c[t] : 0.0;
+                lp[q] = lv.lpos[t];
+            }
         }
-    } else {
-#pragma unroll 4
-        for (int t = tid; t < nf; t += NT) xs[lv.lpos[t]] = xc[t];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int t = tid + q * NT;
+            if (t < nf) {
+                double v = xv[q];
+                if (FUSED) {
+                    if (x2c) v = v + beta * x2v[q];
+                    if (xoc) xoc[t] = v;
+                    rr += v * v;
+                }
+                xs[lp[q]] = v;
+            }
+        }
+        for (int t = tid + SPT * NT; t < nf; t += NT) {   // only for cells larger than SPT*NT
+            double v = xc[t];
+            if (FUSED) {
+                if (x2c) v = v + beta * x2c[t];
+                if (xoc) xoc[t] = v;
+                rr += v * v;
+            }
+            xs[lv.lpos[t]] = v;
+        }
     }
 
     // compact addressing words, fetched two iterations ahead of their use so that the L2 latency of
@@ -314,10 +338,10 @@ size_t apply_lds_bytes(const LevelDev &lv)
     return sizeof(double) * (size_t)(WSZ + lv.lds_g0 + lv.nf + lv.lds_g1);
 }
 
-template <int DIM, int NT, bool FUSED>
+template <int DIM, int NT, int SPT, bool FUSED>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
-    auto kern = k_apply<DIM, NT, FUSED>;
+    auto kern = k_apply<DIM, NT, SPT, FUSED>;
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, a);
@@ -335,13 +359,15 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     int nt = L.apply_threads;
     if (nt == 0) nt = nf <= 64 ? 64 : nf <= 2048 ? 256 : 1024;
     if (nt <= 64)
-        launch_apply_generic<DIM, 64, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 64, 1, FUSED>(L, lv, mesh, a, lds);
+    else if (nt <= 256 && nf <= 1024)
+        launch_apply_generic<DIM, 256, 4, FUSED>(L, lv, mesh, a, lds);
     else if (nt <= 256)
-        launch_apply_generic<DIM, 256, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 256, 8, FUSED>(L, lv, mesh, a, lds);
     else if (nt <= 512)
-        launch_apply_generic<DIM, 512, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
     else
-        launch_apply_generic<DIM, 1024, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 1024, 7, FUSED>(L, lv, mesh, a, lds);
 }
 
 void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
