@@ -4,3 +4,4 @@ from . import _lib  # noqa: F401
 from .api import *  # noqa: F401,F403
 from . import api  # noqa: F401
 from . import driver  # noqa: F401
+from . import dist  # noqa: F401

@@ -22,6 +22,7 @@ SIGNATURES = {
     "hmg_last_error": (ctypes.c_char_p, []),
     "hmg_version": (c_int, []),
     "hmg_ctx_create": (c_int, [c_int, vp, pp]),
+    "hmg_ctx_create_on_stream": (c_int, [c_int, vp, pp]),
     "hmg_ctx_destroy": (c_int, [vp]),
     "hmg_ctx_sync": (c_int, [vp]),
     "hmg_ctx_set_option": (c_int, [vp, ctypes.c_char_p, c_i64]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "hmg_grid_set_cut": (c_int, [vp, c_i64, c_i64, c_i64, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32]),
     "hmg_grid_set_exchange": (c_int, [vp, EXCHANGE_FN, EXCHANGE_FN, vp, vp, c_i64]),
     "hmg_grid_cut_buffer_doubles": (c_i64, [vp, c_int]),
+    "hmg_ctx_set_scalar_bank": (c_int, [vp, vp]),
+    "hmg_grid_create_partition": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, p_i32, c_int, c_int, pp]),
 }
 
 _lib = None

@@ -53,7 +53,10 @@ class Context:
     def __init__(self, device: int = 0, stream=None):
         self._lib = L.load()
         h = ctypes.c_void_p()
-        L.check(self._lib.hmg_ctx_create(device, ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)))
+        if stream is None:
+            L.check(self._lib.hmg_ctx_create(device, None, ctypes.byref(h)))
+        else:   # a raw handle; 0 is torch's default stream
+            L.check(self._lib.hmg_ctx_create_on_stream(device, ctypes.c_void_p(int(stream)), ctypes.byref(h)))
         self.h = h
         self.device = device
 

@@ -122,6 +122,9 @@ struct hmg_grid {
     DevBuf<double> c_val, c_diag, c_b, c_x, c_r, c_z, c_p, c_q, c_u;
     int coarse_last_it = 0;
     // multi-GPU
+    std::unique_ptr<Partition> part;
+    std::vector<double> sigma_global;
+    DevBuf<int32_t> d_nodes_g, d_owned, d_cells_gnode;
     CutKind cut[3];   // faces, edges, nodes
     hmg_exchange_fn exchange = nullptr, scalar_sum = nullptr;
     void *ex_user = nullptr;
@@ -220,9 +223,104 @@ void upload_mesh(hmg_grid *g)
     d.coef = g->d_coef.p;
 }
 
+}  // namespace
+static void upload_levels(hmg_grid *g)
+{
+    hipStream_t s = g->ctx ? g->ctx->stream : nullptr;
+    g->ld.resize(g->nlevels);
+    for (int l = 0; l < g->nlevels; ++l) {
+        const LevelTables &T = g->lt[l];
+        g->lb.emplace_back(new LevelBufs);
+        LevelBufs &B = *g->lb.back();
+        if (g->ctx) {
+            B.meta.upload(T.meta, s);
+            {
+                std::vector<uint16_t> lp(T.meta.size());
+                for (size_t q = 0; q < lp.size(); ++q) lp[q] = (uint16_t)(T.meta[q] & 0xffffu);
+                B.lpos.upload(lp, s);
+            }
+            {
+                // compact addressing word: L | j<<16 | k<<22 | cls<<28  (len, A, B follow from j, k, m)
+                auto pack32 = [&](uint64_t mt, int cls) {
+                    uint32_t Lx = (uint32_t)(mt & 0xffffu), len = (uint32_t)((mt >> 16) & 0xffu);
+                    uint32_t A = (uint32_t)((mt >> 32) & 0xffffu);
+                    // recover j, k: len = m+1-j-k ; A = T_k - j (3D) ; 2D: k = 0
+                    uint32_t k = 0, j = 0;
+                    if (T.dim == 3) {
+                        for (k = 0; k <= (uint32_t)T.m; ++k) {
+                            uint32_t n = T.m - k, Tk = (n + 1) * (n + 2) / 2;
+                            j = T.m + 1 - k - len;
+                            if (Tk - j == A) break;
+                        }
+                    } else
+                        j = T.m + 1 - len;
+                    return Lx | (j << 16) | (k << 22) | ((uint32_t)cls << 28);
+                };
+                std::vector<uint32_t> p32(T.meta.size()), s32(T.sweep_meta.size());
+                for (size_t q = 0; q < p32.size(); ++q) p32[q] = pack32(T.meta[q], T.slot_cls[q]);
+                for (size_t q = 0; q < s32.size(); ++q) s32[q] = pack32(T.sweep_meta[q], 0);
+                B.pos32.upload(p32, s);
+                B.sweep32.upload(s32, s);
+            }
+            B.sweep_meta.upload(T.sweep_meta, s);
+            B.sweep_slot.upload(T.sweep_slot, s);
+            B.ctab.upload(T.ctab, s);
+            B.hier2slot.upload(T.hier2slot, s);
+            B.par_a.upload(T.par_a, s);
+            B.par_b.upload(T.par_b, s);
+            B.rptr.upload(T.rptr, s);
+            B.ridx.upload(T.ridx, s);
+            B.dphi.upload(T.dphi, s);
+        }
+        LevelDev &D = g->ld[l];
+        D.dim = T.dim;
+        D.level = T.level;
+        D.m = T.m;
+        D.nf = T.nf;
+        D.ld = T.ld;
+        D.ncorner = T.ncorner;
+        D.nedge = T.nedge;
+        D.nface = T.nface;
+        D.nei = T.nei;
+        D.nfi = T.nfi;
+        D.nint = T.nint;
+        D.off_edge = T.off_edge;
+        D.off_face = T.off_face;
+        D.off_int = T.off_int;
+        D.ncls = T.ncls;
+        D.ndir = T.ndir;
+        D.nterm = T.nterm;
+        D.lds_g0 = T.lds_g0;
+        D.lds_g1 = T.lds_g1;
+        D.nf_coarse = l > 0 ? g->lt[l - 1].nf : 0;
+        D.meta = B.meta.p;
+        D.lpos = B.lpos.p;
+        D.sweep_meta = B.sweep_meta.p;
+        D.sweep_slot = B.sweep_slot.p;
+        D.pos32 = B.pos32.p;
+        D.sweep32 = B.sweep32.p;
+        D.nsweep = (int)T.sweep_meta.size();
+        D.ctab = B.ctab.p;
+        D.hier2slot = B.hier2slot.p;
+        D.par_a = B.par_a.p;
+        D.par_b = B.par_b.p;
+        D.rptr = B.rptr.p;
+        D.ridx = B.ridx.p;
+        D.dphi = B.dphi.p;
+    }
+}
+namespace {
+
 void upload_operator(hmg_grid *g)
 {
     const MeshTables &M = g->cur();
+    if (g->part) {   // local sigma = rows of the global field
+        const int dim = g->dim;
+        g->sigma.resize((size_t)M.ncells * dim);
+        for (int64_t q = 0; q < M.ncells; ++q)
+            for (int a = 0; a < dim; ++a)
+                g->sigma[(size_t)q * dim + a] = g->sigma_global[(size_t)g->part->cells_g[q] * dim + a];
+    }
     build_cell_coefficients(M, g->sigma.data(), g->coef);
     g->coarse_ready = false;
     if (!g->ctx) return;
@@ -265,7 +363,7 @@ void interface_sum(hmg_grid *g, const LevelDev &lv, double *x)
 void scalar_sum(hmg_grid *g, int slot, int count)
 {
     if (g->scalar_sum) {
-        if (g->scalar_sum(g->ex_user, g->ctx->scal.p + slot, count) != 0)
+        if (g->scalar_sum(g->ex_user, g->ctx->L.scal + slot, count) != 0)
             throw std::runtime_error("scalar_sum callback failed");
     }
 }
@@ -315,21 +413,26 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
     apply(g, lv, -1.0, x->d, b->d, r->d, 1);                            // r = b - A x, constraint
     interface_sum(g, lv, r->d);
     int cur = S_RS, other = S_RS2;
-    if (g->fuse_cg && !g->exchange) {
+    if (g->fuse_cg) {
         // p-update and both reductions ride along with the operator apply (see k_apply<.., FUSED>)
         for (int i = 0; i < steps; ++i) {
-            if (i == 0)
+            if (i == 0) {
                 apply_fused(g, lv, r->d, nullptr, p->d, Ap->d, 0, 0, S_PAP, cur);   // p = r; rs = r.r
-            else
+                scalar_sum(g, cur, 1);
+            } else
                 apply_fused(g, lv, r->d, p->d, p->d, Ap->d, cur, other, S_PAP, -1); // beta = rs'/rs
+            scalar_sum(g, S_PAP, 1);
             interface_sum(g, lv, Ap->d);
-            launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, i == 0 ? other : other);
+            launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);
+            scalar_sum(g, other, 1);
             std::swap(cur, other);
         }
         if (steps > 0)
             launch_cg_pupdate(L, p->d, r->d, n, cur, other);            // the reference's last p-update
-        else
+        else {
             launch_copy_dot(L, p->d, r->d, n, cur);
+            scalar_sum(g, cur, 1);
+        }
         return;
     }
     launch_copy_dot(L, p->d, r->d, n, cur);                              // p = r; rs = r.r
@@ -349,8 +452,8 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
 void coarse_setup(hmg_grid *g)
 {
     need(g->has_op, "hmg_grid_set_operator must be called first");
-    const MeshTables &M = g->cur();
-    assemble_coarse_matrix(M, g->sigma.data(), g->lambda, g->cm);
+    const MeshTables &M = g->part ? g->part->global : g->cur();
+    assemble_coarse_matrix(M, g->part ? g->sigma_global.data() : g->sigma.data(), g->lambda, g->cm);
     if (!g->ctx) return;
     hipStream_t s = g->ctx->stream;
     g->c_rowptr.upload(g->cm.rowptr, s);
@@ -386,7 +489,7 @@ void coarse_pcg(hmg_grid *g)
     if (A.n == 0) return;
     launch_coarse_init(L, A, g->c_b.p, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p);
     double h[S_COUNT];
-    HIPCHK(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h, c->L.scal, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const double bb = h[S_C2];
     if (!(bb > 0.0)) return;   // b == 0 -> x == 0
@@ -400,7 +503,7 @@ void coarse_pcg(hmg_grid *g)
             launch_coarse_pupdate(L, A, g->c_p.p, g->c_z.p);
         }
         it += chunk;
-        HIPCHK(hipMemcpyAsync(h, c->scal.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(h, c->L.scal, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (!(h[S_TMP] > tol2)) break;
         if (!std::isfinite(h[S_TMP])) throw std::runtime_error("coarse PCG diverged (non-finite residual)");
@@ -412,10 +515,24 @@ void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
 {
     // ref: src/multigrid.jl:74-93
     if (!g->coarse_ready) coarse_setup(g);
-    need(!g->exchange, "coarse solve on a partitioned grid goes through the host layer (gather to one rank)");
     const LevelDev &lv = lev(g, 1);
     const Launch &L = g->ctx->L;
     interface_sum(g, lv, b1->d);
+    if (g->part) {
+        // Replicated coarse solve: every rank contributes the nodes it owns to a global nodal vector
+        // (one sum over ranks), solves the whole level-1 system, and scatters to its own cells.
+        need(g->exchange != nullptr, "partitioned grid: hmg_grid_set_exchange must be called before a coarse solve");
+        const int64_t ng = g->part->global.nnodes;
+        need(ng <= g->ex_cap, "exchange buffer too small for the coarse gather");
+        launch_fill(L, g->ex_buf, ng, 0.0);
+        launch_gather_owned(L, g->md, g->d_nodes_g.p, g->d_owned.p, lv.ld, b1->d, g->ex_buf);
+        if (g->exchange(g->ex_user, g->ex_buf, ng) != 0) throw std::runtime_error("exchange callback failed");
+        launch_coarse_gather_rhs(L, g->cd, g->ex_buf, g->c_b.p);
+        coarse_pcg(g);
+        launch_coarse_scatter_sol(L, g->cd, ng, g->c_x.p, g->c_u.p);
+        launch_scatter_cells(L, g->d_cells_gnode.p, g->md.ncells, g->dim + 1, lv.ld, g->c_u.p, x1->d);
+        return;
+    }
     launch_gather_base(L, g->md, lv.ld, b1->d, g->c_u.p);
     launch_coarse_gather_rhs(L, g->cd, g->c_u.p, g->c_b.p);
     coarse_pcg(g);
@@ -487,7 +604,13 @@ extern "C" {
 const char *hmg_last_error(void) { return last_error().c_str(); }
 int hmg_version(void) { return 1; }
 
-int hmg_ctx_create(int device, void *stream, hmg_ctx **out)
+static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out);
+
+int hmg_ctx_create(int device, void *stream, hmg_ctx **out) { return ctx_create(device, stream, stream != nullptr, out); }
+
+int hmg_ctx_create_on_stream(int device, void *stream, hmg_ctx **out) { return ctx_create(device, stream, true, out); }
+
+static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
 {
     HMG_TRY
     need(out != nullptr, "null out pointer");
@@ -499,8 +622,8 @@ int hmg_ctx_create(int device, void *stream, hmg_ctx **out)
     HIPCHK(hipSetDevice(device));
     std::unique_ptr<hmg_ctx> c(new hmg_ctx);
     c->device = device;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
+    if (use_given) {
+        c->stream = (hipStream_t)stream;   // may be the null (legacy default) stream
     } else {
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
@@ -579,7 +702,19 @@ int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value)
     HMG_END
 }
 
-void *hmg_ctx_scalar_bank(hmg_ctx *ctx) { return ctx ? (void *)ctx->scal.p : nullptr; }
+void *hmg_ctx_scalar_bank(hmg_ctx *ctx) { return ctx ? (void *)ctx->L.scal : nullptr; }
+
+/* Replace the library's scalar bank (16 device doubles) by caller-owned device memory, e.g. a torch
+ * tensor that torch.distributed can all-reduce in place. */
+int hmg_ctx_set_scalar_bank(hmg_ctx *ctx, void *device_doubles16)
+{
+    HMG_TRY
+    need(ctx && device_doubles16, "null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(device_doubles16, ctx->L.scal, S_COUNT * sizeof(double), hipMemcpyDeviceToDevice));
+    ctx->L.scal = (double *)device_doubles16;
+    HMG_END
+}
 
 int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, double *total_bytes)
 {
@@ -611,89 +746,44 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
     g->nlevels = nlevels;
     g->lt = build_level_tables(dim, nlevels);
     build_mesh_tables(dim, nnodes, coords, ncells, cells, g->mesh_full);
-    hipStream_t s = ctx ? ctx->stream : nullptr;
-    g->ld.resize(nlevels);
-    for (int l = 0; l < nlevels; ++l) {
-        const LevelTables &T = g->lt[l];
-        g->lb.emplace_back(new LevelBufs);
-        LevelBufs &B = *g->lb.back();
-        if (ctx) {
-            B.meta.upload(T.meta, s);
-            {
-                std::vector<uint16_t> lp(T.meta.size());
-                for (size_t q = 0; q < lp.size(); ++q) lp[q] = (uint16_t)(T.meta[q] & 0xffffu);
-                B.lpos.upload(lp, s);
-            }
-            {
-                // compact addressing word: L | j<<16 | k<<22 | cls<<28  (len, A, B follow from j, k, m)
-                auto pack32 = [&](uint64_t mt, int cls) {
-                    uint32_t Lx = (uint32_t)(mt & 0xffffu), len = (uint32_t)((mt >> 16) & 0xffu);
-                    uint32_t A = (uint32_t)((mt >> 32) & 0xffffu);
-                    // recover j, k: len = m+1-j-k ; A = T_k - j (3D) ; 2D: k = 0
-                    uint32_t k = 0, j = 0;
-                    if (T.dim == 3) {
-                        for (k = 0; k <= (uint32_t)T.m; ++k) {
-                            uint32_t n = T.m - k, Tk = (n + 1) * (n + 2) / 2;
-                            j = T.m + 1 - k - len;
-                            if (Tk - j == A) break;
-                        }
-                    } else
-                        j = T.m + 1 - len;
-                    return Lx | (j << 16) | (k << 22) | ((uint32_t)cls << 28);
-                };
-                std::vector<uint32_t> p32(T.meta.size()), s32(T.sweep_meta.size());
-                for (size_t q = 0; q < p32.size(); ++q) p32[q] = pack32(T.meta[q], T.slot_cls[q]);
-                for (size_t q = 0; q < s32.size(); ++q) s32[q] = pack32(T.sweep_meta[q], 0);
-                B.pos32.upload(p32, s);
-                B.sweep32.upload(s32, s);
-            }
-            B.sweep_meta.upload(T.sweep_meta, s);
-            B.sweep_slot.upload(T.sweep_slot, s);
-            B.ctab.upload(T.ctab, s);
-            B.hier2slot.upload(T.hier2slot, s);
-            B.par_a.upload(T.par_a, s);
-            B.par_b.upload(T.par_b, s);
-            B.rptr.upload(T.rptr, s);
-            B.ridx.upload(T.ridx, s);
-            B.dphi.upload(T.dphi, s);
-        }
-        LevelDev &D = g->ld[l];
-        D.dim = T.dim;
-        D.level = T.level;
-        D.m = T.m;
-        D.nf = T.nf;
-        D.ld = T.ld;
-        D.ncorner = T.ncorner;
-        D.nedge = T.nedge;
-        D.nface = T.nface;
-        D.nei = T.nei;
-        D.nfi = T.nfi;
-        D.nint = T.nint;
-        D.off_edge = T.off_edge;
-        D.off_face = T.off_face;
-        D.off_int = T.off_int;
-        D.ncls = T.ncls;
-        D.ndir = T.ndir;
-        D.nterm = T.nterm;
-        D.lds_g0 = T.lds_g0;
-        D.lds_g1 = T.lds_g1;
-        D.nf_coarse = l > 0 ? g->lt[l - 1].nf : 0;
-        D.meta = B.meta.p;
-        D.lpos = B.lpos.p;
-        D.sweep_meta = B.sweep_meta.p;
-        D.sweep_slot = B.sweep_slot.p;
-        D.pos32 = B.pos32.p;
-        D.sweep32 = B.sweep32.p;
-        D.nsweep = (int)T.sweep_meta.size();
-        D.ctab = B.ctab.p;
-        D.hier2slot = B.hier2slot.p;
-        D.par_a = B.par_a.p;
-        D.par_b = B.par_b.p;
-        D.rptr = B.rptr.p;
-        D.ridx = B.ridx.p;
-        D.dphi = B.dphi.p;
-    }
+    upload_levels(g.get());
     upload_mesh(g.get());
+    *out = g.release();
+    HMG_END
+}
+
+static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const int64_t *gid, const int32_t *cell_lid);
+static void upload_levels(hmg_grid *g);
+
+int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
+                              const int64_t *cells, const int32_t *owner, int rank, int nranks, hmg_grid **out)
+{
+    HMG_TRY
+    need(coords && cells && owner && out, "null argument");
+    if (ctx) HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<hmg_grid> g(new hmg_grid);
+    g->ctx = ctx;
+    g->fuse_cg = ctx ? ctx->fuse_cg_default : true;
+    g->dim = dim;
+    g->nlevels = nlevels;
+    g->lt = build_level_tables(dim, nlevels);
+    g->part.reset(new Partition);
+    build_partition(dim, nnodes, coords, ncells, cells, owner, rank, nranks, g->mesh_full, *g->part);
+    upload_levels(g.get());
+    upload_mesh(g.get());
+    for (int k = 0; k < 3; ++k) g->cut[k].nglobal = g->part->nglobal[k];
+    if (ctx) {
+        const Partition &P = *g->part;
+        for (int k = 0; k < 3; ++k)
+            set_cut_kind(g.get(), k, P.nglobal[k], (int64_t)P.gid[k].size(), P.gid[k].data(), P.cell_lid[k].data());
+        g->d_nodes_g.upload(P.nodes_g, ctx->stream);
+        g->d_owned.upload(P.owned_node, ctx->stream);
+        const int N = dim + 1;
+        std::vector<int32_t> cg(g->mesh_full.cells.size());
+        for (size_t q = 0; q < cg.size(); ++q) cg[q] = P.nodes_g[g->mesh_full.cells[q]];
+        (void)N;
+        g->d_cells_gnode.upload(cg, ctx->stream);
+    }
     *out = g.release();
     HMG_END
 }
@@ -712,7 +802,10 @@ int hmg_grid_set_operator(hmg_grid *g, const double *sigma, double lambda)
 {
     HMG_TRY
     need(g && sigma, "null argument");
-    g->sigma.assign(sigma, sigma + (size_t)g->mesh_full.ncells * g->dim);
+    if (g->part)
+        g->sigma_global.assign(sigma, sigma + (size_t)g->part->global.ncells * g->dim);
+    else
+        g->sigma.assign(sigma, sigma + (size_t)g->mesh_full.ncells * g->dim);
     g->lambda = lambda;
     g->has_op = true;
     upload_operator(g);
@@ -732,7 +825,7 @@ int hmg_grid_shrink(hmg_grid *g, int64_t ncells_prefix, int64_t nnodes_prefix)
 {
     HMG_TRY
     need(g != nullptr, "null grid");
-    need(!g->exchange, "shrink on a partitioned grid is not supported yet");
+    need(!g->part, "shrink on a partitioned grid is not supported yet");
     restrict_mesh_tables(g->mesh_full, ncells_prefix, nnodes_prefix, g->mesh);
     g->shrunk = true;
     upload_mesh(g);
@@ -779,6 +872,32 @@ int hmg_grid_table_i32(const hmg_grid *g, int level, const char *which, int32_t 
         src = &g->cm.rowptr;
     } else if (w == "coarse_colidx") {
         src = &g->cm.colidx;
+    } else if (w == "part_cells") {
+        need(g->part != nullptr, "not a partitioned grid");
+        src = &g->part->cells_g;
+    } else if (w == "part_nodes") {
+        need(g->part != nullptr, "not a partitioned grid");
+        src = &g->part->nodes_g;
+    } else if (w == "part_owned") {
+        need(g->part != nullptr, "not a partitioned grid");
+        src = &g->part->owned_node;
+    } else if (w == "cut_counts") {
+        need(g->part != nullptr, "not a partitioned grid");
+        tmp = {(int32_t)g->part->nglobal[0], (int32_t)g->part->nglobal[1], (int32_t)g->part->nglobal[2],
+               (int32_t)g->part->gid[0].size(), (int32_t)g->part->gid[1].size(), (int32_t)g->part->gid[2].size()};
+        src = &tmp;
+    } else if (w == "cut_gid_faces" || w == "cut_gid_edges" || w == "cut_gid_nodes" || w == "cut_ent_faces" ||
+               w == "cut_ent_edges" || w == "cut_ent_nodes") {
+        need(g->part != nullptr, "not a partitioned grid");
+        const int k = w.find("faces") != std::string::npos ? 0 : w.find("edges") != std::string::npos ? 1 : 2;
+        if (w.find("gid") != std::string::npos)
+            tmp.assign(g->part->gid[k].begin(), g->part->gid[k].end());
+        else
+            tmp = g->part->cell_lid[k];
+        src = &tmp;
+    } else if (w == "mult") {
+        tmp.assign(g->cur().mult.begin(), g->cur().mult.end());
+        src = &tmp;
     } else if (w == "interior_nodes") {
         const MeshTables &M = g->cur();
         for (int64_t i = 0; i < M.nnodes; ++i)
@@ -979,7 +1098,7 @@ int hmg_vec_xpby(hmg_vec *r, double beta, hmg_vec *p)
 static double read_scalar(hmg_ctx *c, int slot)
 {
     double h = 0.0;
-    HIPCHK(hipMemcpyAsync(&h, c->scal.p + slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&h, c->L.scal + slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return h;
 }
@@ -999,8 +1118,8 @@ int hmg_vec_norm_unique(hmg_vec *r, double *out)
 {
     HMG_TRY
     need(r && out, "null argument");
-    need(!r->g->exchange, "norm_unique on a partitioned grid goes through the host layer");
     launch_norm2_unique(r->g->ctx->L, lev(r->g, r->level), r->g->md, r->d, S_TMP);
+    scalar_sum(r->g, S_TMP, 1);
     *out = std::sqrt(read_scalar(r->g->ctx, S_TMP));
     HMG_END
 }
@@ -1248,7 +1367,12 @@ int hmg_grid_set_exchange(hmg_grid *g, hmg_exchange_fn exchange, hmg_exchange_fn
 
 int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *g, int level)
 {
-    if (!g || level < 1 || level > g->nlevels) return -1;
+    if (!g || level < 0 || level > g->nlevels) return -1;
+    if (level == 0) {   // required capacity: max over levels and the coarse gather
+        int64_t n = g->part ? g->part->global.nnodes : 0;
+        for (int l = 0; l < g->nlevels; ++l) n = std::max(n, cut_doubles(g, g->ld[l]));
+        return n;
+    }
     return cut_doubles(g, g->ld[level - 1]);
 }
 

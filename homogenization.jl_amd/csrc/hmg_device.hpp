@@ -115,6 +115,11 @@ void launch_cg_pupdate(const Launch &L, double *p, const double *r, int64_t n, i
 void launch_gather_base(const Launch &L, const MeshDev &mesh, int ld1, const double *v1, double *u);
 void launch_scatter_base(const Launch &L, const MeshDev &mesh, int ld1, const double *u, double *v1);
 
+void launch_gather_owned(const Launch &L, const MeshDev &mesh, const int32_t *nodes_g, const int32_t *owned, int ld1,
+                         const double *v1, double *ug);
+void launch_scatter_cells(const Launch &L, const int32_t *cell_nodes, int64_t ncells, int npc, int ld1, const double *u,
+                          double *v1);
+
 void launch_permute(const Launch &L, const LevelDev &lv, int64_t ncells, const double *src, double *dst,
                     int to_storage);
 void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, double *x, uint64_t seed,

@@ -127,6 +127,26 @@ struct CoarseMatrix {
 void assemble_coarse_matrix(const MeshTables &mesh, const double *sigma, double lambda,
                             CoarseMatrix &out);
 
+// ---------------------------------------------------------------------------------------------
+// Partition by coarse-cell ownership (one rank per GPU).
+// ---------------------------------------------------------------------------------------------
+struct Partition {
+    int rank = 0, nranks = 1;
+    MeshTables global;                       // the whole base mesh (kept for the replicated coarse solve)
+    std::vector<int32_t> cells_g;            // global id of every local cell (ascending)
+    std::vector<int32_t> nodes_g;            // global id of every local node (ascending)
+    std::vector<int32_t> owned_node;         // per local node: 1 if its globally first copy is in a local cell
+    // entities shared between ranks: global cut id + local copy, per kind (0 faces, 1 edges, 2 nodes)
+    int64_t nglobal[3] = {0, 0, 0};
+    std::vector<int64_t> gid[3];
+    std::vector<int32_t> cell_lid[3];
+};
+
+// Splits `global` by owner[cell] and fills `local` (tables of this rank's cells, with Dirichlet mask,
+// duplicate mask and multiplicities taken from the GLOBAL mesh) and `part`.
+void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells_1based,
+                     const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part);
+
 std::string &last_error();
 
 }  // namespace hmg

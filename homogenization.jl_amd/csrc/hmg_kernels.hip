@@ -861,6 +861,33 @@ k_scatter_base(const int32_t *__restrict__ cells, int64_t ncells, int npc, int l
     v1[c * ld1 + l] = u[cells[i]];
 }
 
+// partitioned gather: u_global[nodes_g[q]] = v1[first local copy of local node q], owned nodes only
+__global__ void __launch_bounds__(256)
+k_gather_owned(const int32_t *__restrict__ node_first, const int32_t *__restrict__ nodes_g,
+               const int32_t *__restrict__ owned, int64_t nlocal, int ld1, const double *__restrict__ v1, double *ug)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nlocal || !owned[q]) return;
+    const int32_t v = node_first[q];
+    ug[nodes_g[q]] = v1[(int64_t)(v >> 3) * ld1 + (v & 7)];
+}
+
+void launch_gather_owned(const Launch &L, const MeshDev &mesh, const int32_t *nodes_g, const int32_t *owned, int ld1,
+                         const double *v1, double *ug)
+{
+    hipLaunchKernelGGL(k_gather_owned, dim3((unsigned)((mesh.nnodes + 255) / 256)), dim3(256), 0, L.stream,
+                       mesh.node_first, nodes_g, owned, mesh.nnodes, ld1, v1, ug);
+    check_launch();
+}
+
+void launch_scatter_cells(const Launch &L, const int32_t *cell_nodes, int64_t ncells, int npc, int ld1, const double *u,
+                          double *v1)
+{
+    hipLaunchKernelGGL(k_scatter_base, dim3((unsigned)((ncells * npc + 255) / 256)), dim3(256), 0, L.stream,
+                       cell_nodes, ncells, npc, ld1, u, v1);
+    check_launch();
+}
+
 void launch_gather_base(const Launch &L, const MeshDev &mesh, int ld1, const double *v1, double *u)
 {
     hipLaunchKernelGGL(k_gather_base, dim3((unsigned)((mesh.nnodes + 255) / 256)), dim3(256), 0, L.stream,

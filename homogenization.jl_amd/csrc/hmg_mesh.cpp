@@ -257,6 +257,80 @@ void restrict_mesh_tables(const MeshTables &full, int64_t ncells_prefix, int64_t
     build_from_cells0(M);
 }
 
+void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells_1based,
+                     const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part)
+{
+    part.rank = rank;
+    part.nranks = nranks;
+    MeshTables &G = part.global;
+    build_mesh_tables(dim, nnodes, coords, ncells, cells_1based, G);
+    const int N = dim + 1;
+    const int nface = dim == 3 ? 4 : 0, nedge = dim == 3 ? 6 : 3;
+
+    // local cells / nodes in ascending global order (keeps every cell tuple ascending)
+    std::vector<int32_t> cell_l(ncells, -1), node_l(nnodes, -1);
+    part.cells_g.clear();
+    for (int64_t c = 0; c < ncells; ++c) {
+        if (owner[c] < 0 || owner[c] >= nranks) throw std::runtime_error("partition: owner out of range");
+        if (owner[c] == rank) {
+            cell_l[c] = (int32_t)part.cells_g.size();
+            part.cells_g.push_back((int32_t)c);
+            for (int l = 0; l < N; ++l) node_l[G.cells[c * N + l]] = 0;
+        }
+    }
+    if (part.cells_g.empty()) throw std::runtime_error("partition: this rank owns no cell");
+    part.nodes_g.clear();
+    for (int64_t g = 0; g < nnodes; ++g)
+        if (node_l[g] == 0) {
+            node_l[g] = (int32_t)part.nodes_g.size();
+            part.nodes_g.push_back((int32_t)g);
+        }
+    std::vector<double> lc((size_t)part.nodes_g.size() * dim);
+    for (size_t q = 0; q < part.nodes_g.size(); ++q)
+        for (int a = 0; a < dim; ++a) lc[q * dim + a] = coords[(size_t)part.nodes_g[q] * dim + a];
+    std::vector<int64_t> lcells((size_t)part.cells_g.size() * N);
+    for (size_t q = 0; q < part.cells_g.size(); ++q)
+        for (int l = 0; l < N; ++l) lcells[q * N + l] = (int64_t)node_l[G.cells[(size_t)part.cells_g[q] * N + l]] + 1;
+    build_mesh_tables(dim, (int64_t)part.nodes_g.size(), lc.data(), (int64_t)part.cells_g.size(), lcells.data(), local);
+
+    // masks and multiplicities are properties of the GLOBAL mesh
+    for (size_t q = 0; q < part.cells_g.size(); ++q) {
+        const int64_t c = part.cells_g[q];
+        local.dmask[q] = G.dmask[c];
+        local.dupmask[q] = G.dupmask[c];
+        for (int b = 0; b < 16; ++b) local.mult[q * 16 + b] = G.mult[(size_t)c * 16 + b];
+    }
+    part.owned_node.assign(part.nodes_g.size(), 0);
+    for (size_t q = 0; q < part.nodes_g.size(); ++q) {
+        const int32_t first = G.node_first[part.nodes_g[q]];
+        part.owned_node[q] = first >= 0 && owner[first >> 3] == rank;
+        local.node_on_boundary[q] = G.node_on_boundary[part.nodes_g[q]];
+    }
+
+    // entities whose copies live on more than one rank get a global cut id (same on every rank)
+    for (int kind = 0; kind < 3; ++kind) {
+        part.nglobal[kind] = 0;
+        part.gid[kind].clear();
+        part.cell_lid[kind].clear();
+        if (kind == 0 && dim != 3) continue;
+        auto ents = list_entities(G, kind == 0 ? 2 : kind == 1 ? 1 : 0);
+        (void)nface;
+        (void)nedge;
+        for_groups(ents, [&](size_t i, size_t j) {
+            bool cut = false;
+            for (size_t q = i + 1; q < j; ++q)
+                if (owner[ents[q].cell] != owner[ents[i].cell]) cut = true;
+            if (!cut) return;
+            const int64_t id = part.nglobal[kind]++;
+            for (size_t q = i; q < j; ++q)
+                if (owner[ents[q].cell] == rank) {
+                    part.gid[kind].push_back(id);
+                    part.cell_lid[kind].push_back(cell_l[ents[q].cell] * 8 + ents[q].lid);
+                }
+        });
+    }
+}
+
 void build_cell_coefficients(const MeshTables &M, const double *sigma, std::vector<double> &coef)
 {
     const int dim = M.dim;

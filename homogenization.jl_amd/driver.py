@@ -40,6 +40,31 @@ def hypercube(eltype, n: int, scale=1.0, origin=None) -> Mesh:
     return Mesh(nodes, cells.astype(np.int64))
 
 
+def box_mesh(eltype, shape, scale=1.0, origin=None) -> Mesh:
+    """A box of shape[0] x shape[1] (x shape[2]) unit cubes, each split into 6 tetrahedra / 2 triangles around
+    one diagonal like `hypercube` (node ids run with the last coordinate fastest).  Used for multi-GPU weak
+    scaling, where the global domain is a brick of per-rank cubes; not a reference entry point."""
+    dim = api._dim_of(eltype)
+    shape = tuple(int(v) for v in shape)
+    assert len(shape) == dim
+    origin = np.ones(dim) if origin is None else np.asarray(origin, dtype=np.float64)
+    k = np.array(shape) + 1
+    grid = np.indices(tuple(k)).reshape(dim, -1).T.astype(np.float64)
+    nodes = scale * grid + origin
+    strides = np.concatenate([[1], np.cumprod(k[:-1])])
+    cube = np.indices(shape).reshape(dim, -1).T
+    corner = np.array([[(c >> a) & 1 for a in range(dim)] for c in range(2 ** dim)])
+    ids = (cube[:, None, :] + corner[None, :, :]) @ strides
+    # node ids run with the LAST coordinate fastest, the lookup table with the FIRST: translate
+    lut = np.ravel_multi_index(np.unravel_index(np.arange(int(np.prod(k))), tuple(k), order="F"), tuple(k), order="C")
+    ids = lut[ids]
+    if dim == 3:
+        cells = ids[:, np.array(_CUBE_TETS)].reshape(-1, 4)
+    else:
+        cells = ids[:, np.array(((0, 1, 2), (1, 2, 3)))].reshape(-1, 3)
+    return Mesh(nodes, (np.sort(cells, axis=1) + 1).astype(np.int64))
+
+
 def _infnorm(a):
     return np.abs(a).max(axis=-1)
 

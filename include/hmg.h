@@ -37,6 +37,9 @@ int hmg_version(void);
 /* ---- context ------------------------------------------------------------------------------ */
 /* stream: a hipStream_t owned by the caller (e.g. torch's current stream) or NULL to create one. */
 int hmg_ctx_create(int device, void *stream, hmg_ctx **out);
+/* Always runs on the given stream handle, including the null (legacy default) stream -- the handle
+ * torch.cuda.current_stream().cuda_stream returns for torch's default stream. */
+int hmg_ctx_create_on_stream(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_destroy(hmg_ctx *ctx);
 int hmg_ctx_sync(hmg_ctx *ctx);
 /* option names: "apply_variant" (0 generic, 1 persistent), "apply_threads", "coarse_maxit",
@@ -142,8 +145,16 @@ int hmg_grid_set_cut(hmg_grid *grid, int64_t ncut_global_faces, int64_t ncut_glo
                      int64_t nlocal_nodes, const int64_t *node_gid, const int32_t *node_cell_lid);
 int hmg_grid_set_exchange(hmg_grid *grid, hmg_exchange_fn exchange, hmg_exchange_fn scalar_sum, void *user,
                           void *device_exchange_buf, int64_t exchange_buf_doubles);
+/* level = 0: capacity needed for every level and for the coarse gather */
 int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *grid, int level);
 void *hmg_ctx_scalar_bank(hmg_ctx *ctx);
+int hmg_ctx_set_scalar_bank(hmg_ctx *ctx, void *device_doubles16);
+/* Grid of the cells owner[c] == rank of a global base mesh.  The library derives the local mesh, the cut
+ * entities (global ids identical on all ranks), global multiplicities and Dirichlet / first-copy masks, and
+ * keeps the global mesh for a replicated level-1 solve.  hmg_grid_set_operator takes the GLOBAL sigma.
+ * hmg_grid_set_cut is called internally; the host only supplies hmg_grid_set_exchange. */
+int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
+                              const int64_t *cells, const int32_t *owner, int rank, int nranks, hmg_grid **out);
 
 #ifdef __cplusplus
 }

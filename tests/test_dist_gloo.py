@@ -1,0 +1,161 @@
+"""
+Multi-rank path on CPU (gloo, world_size 2 and 4): the library's partition analysis (C++ host code:
+local meshes, global cut ids, global multiplicities and masks, node ownership for the replicated coarse
+solve) driven through the same cut tables the device pack/unpack kernels use.  The per-rank compute is
+done with the oracle here (test infrastructure), the exchange is a real torch.distributed all_reduce.
+Checked against the serial oracle on the global mesh.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dim, shape, levels, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        import homogenization_jl_amd as hmg
+        from homogenization_jl_amd import driver, dist as hdist
+        from oracle import oracle as O
+        O.NTHREADS[0] = 1
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        tag = hmg.Tet64 if dim == 3 else hmg.Tri64
+        origin = tuple(-s / 2.0 for s in shape)
+        base = driver.order_nodes_and_elements_by_magnitude(driver.box_mesh(tag, shape, origin=origin))
+        blocks = hdist.block_shape(world, dim)
+        width = shape[0] // blocks[0]
+        owner = hdist.block_owner(base, blocks, width, origin)
+        g = hdist.PartitionedGrid(None, base, levels, owner, rank, world)
+        gm = O.Mesh(base.nodes, base.elements - 1)
+        lm = O.Mesh(g.base.nodes, g.base.elements - 1)
+        rng = np.random.default_rng(7)
+        sig = rng.choice([1.0, 9.0], size=(gm.nelements(), dim))
+        lam, L = 0.8, levels
+        gi = O.ImplicitFineGrid.create(gm, levels)
+        li = O.ImplicitFineGrid(levels, gi.reference, O.interfaces(lm), lm)
+        lvl = gi.reference.levels[-1]
+        diff, mass = O.build_local_diffusion_operators(lvl), O.mass_matrix(lvl)
+        gA = O.L2PlusDivAGrad(diff, mass, None, lam, sig)
+        lA = O.L2PlusDivAGrad(diff, mass, None, lam, sig[g.local_cells])
+        nf = gi.nf(L)
+        x = np.asfortranarray(rng.standard_normal((nf, gm.nelements())))
+        O.broadcast_interfaces(x, gi, L)                                  # consistent input
+        # serial reference
+        y = np.zeros_like(x, order="F"); O.mul(1.0, gm, gA, x, y)
+        cons = O.ZeroDirichletConstraint(*O.list_boundary_nodes_edges_faces(gm))
+        O.apply_constraint(y, L, cons, gi)
+        ysum = y.copy(order="F"); O.broadcast_interfaces(ysum, gi, L)
+        # this rank
+        xl = np.asfortranarray(x[:, g.local_cells])
+        yl = np.zeros_like(xl, order="F"); O.mul(1.0, lm, lA, xl, yl)
+        lay = g.table_i32("layout", L)
+        nface, nedge = lay[4], lay[3]
+        nei, nfi, off_edge, off_face = lay[5], lay[6], lay[8], lay[9]
+        s2h = np.argsort(g.table_i32("hier2slot", L))
+        dmask = g.table_i32("dmask")
+        ent = []                                                          # (bit, slots) of every entity
+        for f in range(nface):
+            ent.append(off_face + f * nfi + np.arange(nfi))
+        for e in range(nedge):
+            ent.append(off_edge + e * nei + np.arange(nei))
+        for c in range(dim + 1):
+            ent.append(np.array([c]))
+        for bit, slots in enumerate(ent):                                 # Dirichlet mask from the GLOBAL boundary
+            cells = np.flatnonzero((dmask >> bit) & 1)
+            yl[np.ix_(s2h[slots], cells)] = 0.0
+        np.testing.assert_array_equal(yl == 0.0, y[:, g.local_cells] == 0.0)
+        # fused-CG identity with GLOBAL multiplicities:  sum mult*x*y_local == dot(x, S y)
+        mult = g.table_i32("mult").reshape(-1, 16)
+        w = np.ones_like(xl)
+        for bit, slots in enumerate(ent):
+            w[s2h[slots], :] = mult[:, bit][None, :]
+        t = torch.tensor([float((w * xl * yl).sum()), float(np.vdot(xl, xl))], dtype=torch.float64)
+        dist.all_reduce(t)
+        assert abs(t[0].item() - float(np.vdot(x, ysum))) <= 1e-10 * abs(float(np.vdot(x, ysum)))
+        assert abs(t[1].item() - float(np.vdot(x, x))) <= 1e-12 * float(np.vdot(x, x))
+        # local interface sum, then the cut exchange exactly as the library packs / unpacks it
+        O.broadcast_interfaces(yl, li, L)
+        counts = g.table_i32("cut_counts")
+        per = {"faces": nfi, "edges": nei, "nodes": 1}
+        offs = {"faces": off_face, "edges": off_edge, "nodes": 0}
+        tot = counts[0] * nfi + counts[1] * nei + counts[2]
+        assert tot <= g.exchange_doubles()
+        buf = torch.zeros(max(tot, 1), dtype=torch.float64)
+        base_off = {"faces": 0, "edges": counts[0] * nfi, "nodes": counts[0] * nfi + counts[1] * nei}
+        views = {}
+        for kind in ("faces", "edges", "nodes"):
+            gid = g.table_i32("cut_gid_" + kind).astype(np.int64)
+            ce = g.table_i32("cut_ent_" + kind).astype(np.int64)
+            if per[kind] == 0 or gid.size == 0:
+                continue
+            k = np.arange(per[kind])
+            slots = offs[kind] + (ce & 7)[:, None] * per[kind] + k[None, :]
+            rows, cols = s2h[slots], (ce >> 3)[:, None] + 0 * k[None, :]
+            dst = base_off[kind] + gid[:, None] * per[kind] + k[None, :]
+            first = np.zeros(gid.size, dtype=bool)
+            first[np.unique(gid, return_index=True)[1]] = True
+            buf[torch.from_numpy(dst[first].ravel())] = torch.from_numpy(yl[rows[first], cols[first]].ravel())
+            views[kind] = (rows, cols, dst)
+        dist.all_reduce(buf)
+        for kind, (rows, cols, dst) in views.items():
+            yl[rows, cols] = buf[torch.from_numpy(dst.ravel())].numpy().reshape(dst.shape)
+        err = np.abs(yl - ysum[:, g.local_cells]).max() / np.abs(ysum).max()
+        assert err <= 1e-13, err
+        # first-copy masks give each DOF exactly once across ranks
+        dup = g.table_i32("dupmask")
+        uniq = np.ones_like(xl)
+        for bit, slots in enumerate(ent):
+            uniq[np.ix_(s2h[slots], np.flatnonzero((dup >> bit) & 1))] = 0.0
+        t = torch.tensor([float((uniq * ysum[:, g.local_cells] ** 2).sum())], dtype=torch.float64)
+        dist.all_reduce(t)
+        ref = ysum.copy(order="F"); O.zero_out_all_but_one(ref, gi, L)
+        assert abs(t.item() - float(np.vdot(ref, ref))) <= 1e-11 * float(np.vdot(ref, ref))
+        # node ownership for the replicated coarse solve: every global node owned exactly once
+        own = torch.zeros(gm.nnodes(), dtype=torch.float64)
+        own[torch.from_numpy(g.local_nodes[g.table_i32("part_owned") == 1])] = 1.0
+        dist.all_reduce(own)
+        assert bool((own == 1.0).all())
+        # global coarse matrix is available on every rank
+        g.set_operator(sig, lam)
+        g.coarse_setup()
+        import scipy.sparse as sp
+        interior = O.list_interior_nodes(gm)
+        want = O.assemble_checkerboard(gm, sig, lam).tocsr()[interior][:, interior]
+        got = sp.csr_matrix((g.table_f64("coarse_val"), g.table_i32("coarse_colidx"), g.table_i32("coarse_rowptr")),
+                            shape=want.shape)
+        assert abs(got - want).max() <= 1e-13 * abs(want).max()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:                                                # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,dim,shape,levels", [(2, 3, (4, 2, 2), 4), (4, 3, (4, 4, 2), 3), (2, 2, (6, 3), 4)])
+def test_partitioned_interface_sum_matches_serial(world, dim, shape, levels):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dim, shape, levels, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in sorted(res):
+        assert msg == "ok", f"rank {rank}: {msg}"

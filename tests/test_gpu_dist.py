@@ -1,0 +1,89 @@
+"""
+Two ranks sharing the one GPU of the test box (gloo all-reduces device tensors through the host): the
+full device path of the partitioned solver -- pack / exchange / unpack after every interface sum, summed
+CG scalars, fused CG pass with global multiplicities, replicated coarse solve -- against the serial
+oracle V-cycle on the global mesh.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, width, levels, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        import homogenization_jl_amd as hmg
+        from homogenization_jl_amd import dist as hdist
+        from oracle import oracle as O
+        O.NTHREADS[0] = 2
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        ctx = hmg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        prob = hdist.partitioned_checkerboard(ctx, width, levels, world, rank, seed=3)
+        g = prob.implicit
+        L = levels
+        # serial oracle on the global mesh with the same inputs
+        gm = O.Mesh(prob.global_base.nodes, prob.global_base.elements - 1)
+        gi = O.ImplicitFineGrid.create(gm, L)
+        cons = O.ZeroDirichletConstraint(*O.list_boundary_nodes_edges_faces(gm))
+        ops = [O.L2PlusDivAGrad(O.build_local_diffusion_operators(l), O.mass_matrix(l), cons, 1.0, prob.cond)
+               for l in gi.reference.levels]
+        sts = [O.LevelState.create(gm.nelements(), gi.nf(i + 1)) for i in range(L)]
+        rng = np.random.default_rng(5)
+        sts[-1].x[...] = rng.random(sts[-1].x.shape)
+        sts[-1].b[...] = rng.standard_normal(sts[-1].x.shape)
+        O.broadcast_interfaces(sts[-1].x, gi, L)
+        O.apply_constraint(sts[-1].x, L, cons, gi)
+        x0, b0 = sts[-1].x.copy(order="F"), sts[-1].b.copy(order="F")
+        base = O.make_base_level(gm, prob.cond, 1.0)
+        dsts = [hmg.LevelState(g, i + 1) for i in range(L)]
+        dsts[-1].x.from_host(x0[:, g.local_cells])
+        dsts[-1].b.from_host(b0[:, g.local_cells])
+        dbase = prob.base_level()
+        for cyc in range(2):
+            O.vcycle(gi, base, ops, sts, L, 3)
+            hmg.vcycle(g, dbase, [prob.op] * L, dsts, L, 3)
+            got = dsts[-1].x.to_host()
+            want = sts[-1].x[:, g.local_cells]
+            err = np.abs(got - want).max() / np.abs(sts[-1].x).max()
+            assert err <= 1e-9, (cyc, err)
+        r = sts[-1].r.copy(order="F")
+        O.zero_out_all_but_one(r, gi, L)
+        assert abs(hmg.norm_unique(dsts[-1].r) - np.linalg.norm(r)) <= 1e-8 * np.linalg.norm(r)
+        assert prob.exchange.calls > 0
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:                                                    # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def test_two_rank_vcycle_matches_serial_oracle():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 2, 4, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in sorted(res):
+        assert msg == "ok", f"rank {rank}: {msg}"
