@@ -84,11 +84,17 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if os.environ.get("HMG_SINGLE_DEVICE") == "1":      # rehearsal of the N>1 path on a 1-GPU box (gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("HMG_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = hmg.Context(local_rank, stream=stream)
@@ -136,7 +142,7 @@ def main():
     dt = time.perf_counter() - t0
     launches, ms, nbytes = ctx.apply_timing()
     ctx.set_option("time_apply", 0)
-    rnorm = hmg.norm_unique(top.r) if world == 1 else float("nan")
+    rnorm = hmg.norm_unique(top.r)            # first copies only; summed over ranks by the library
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -153,11 +159,14 @@ def main():
         value = nf * ne_total * args.steps / dt
         avg_ms = ms / max(launches, 1)
         achieved = (nbytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        traffic = None
+        # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled
+        # as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); cannot be collected inside this process.
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "apply_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1 and w == 32 and L == 6:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc))
+                traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
             except Exception:
                 traffic = None
         out = {
@@ -178,9 +187,10 @@ def main():
                        "coarse_solver": "device Jacobi-PCG rtol 1e-13",
                        "coarse_iterations_last": base_level.last_iterations() if world == 1 else None,
                        "residual_norm_after": rnorm},
-            "roofline": {"bound": "hbm", "kernel": "k_apply_persist (finest-level operator apply)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "hmg::k_apply<3,1024,7,*> (finest-level operator apply: 3 residual + 6 fused CG passes per V-cycle)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": nbytes / max(launches, 1)},
         }
