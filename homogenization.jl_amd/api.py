@@ -340,6 +340,32 @@ def next_rhs(b: DeviceMatrix, x: DeviceMatrix, implicit: ImplicitFineGrid):
     L.check(L.load().hmg_next_rhs(implicit.h, x.h, b.h))
 
 
+def _integrate(implicit, mode, v, vprev, nsub, xi):
+    out = ctypes.c_double()
+    xp = None
+    if xi is not None:
+        xi = np.ascontiguousarray(xi, dtype=np.float64)
+        xp = xi.ctypes.data_as(L.p_f64)
+    L.check(L.load().hmg_integrate(implicit.h, mode, v.h if v is not None else None,
+                                   vprev.h if vprev is not None else None, int(nsub), xp, ctypes.byref(out)))
+    return out.value
+
+
+def integrate_first_term(v0: DeviceMatrix, implicit: ImplicitFineGrid, nsubset: int, xi) -> float:
+    """sum over the first `nsubset` cells of |J| * v0.(dphi.P + M v0)  (src/examples/homogenized_coefficients.jl:592-632)"""
+    return _integrate(implicit, 0, v0, None, nsubset, xi)
+
+
+def integrate_terms(vk: DeviceMatrix, vkm1: DeviceMatrix, implicit: ImplicitFineGrid, nsubset: int) -> float:
+    """sum |J| * (vk + vkm1).(M vk)  (src/examples/homogenized_coefficients.jl:634-667)"""
+    return _integrate(implicit, 1, vk, vkm1, nsubset, None)
+
+
+def integrate_area(v: DeviceMatrix, implicit: ImplicitFineGrid, nsubset: int) -> float:
+    """1' M 1 under the selected cells  (src/examples/homogenized_coefficients.jl:673-689)"""
+    return _integrate(implicit, 2, v, None, nsubset, None)
+
+
 def smoothing_steps(steps, implicit, ops, curr: LevelState, k: int):
     L.check(L.load().hmg_smooth(implicit.h, k, steps, curr.x.h, curr.b.h, curr.r.h, curr.p.h, curr.Ap.h))
 

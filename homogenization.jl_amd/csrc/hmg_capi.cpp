@@ -599,6 +599,8 @@ void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x)
 }  // namespace
 
 // =============================================================================================
+static double read_scalar(hmg_ctx *c, int slot);
+
 extern "C" {
 
 const char *hmg_last_error(void) { return last_error().c_str(); }
@@ -1253,6 +1255,58 @@ int hmg_rhs_axi_grad(hmg_grid *g, const double *xi, hmg_vec *b)
     d.upload(pv, g->ctx->stream);
     launch_rhs_dphi(g->ctx->L, lev(g, b->level), M.ncells, d.p, b->d);
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    HMG_END
+}
+
+static std::vector<double> axi_pvec(const hmg_grid *g, const MeshTables &M, const double *xi, int64_t ncells)
+{
+    // P = -detJ * (Jinv' * (sigma .* xi))   (ref: ...homogenized_coefficients.jl:468, :611)
+    const int dim = g->dim;
+    std::vector<double> pv((size_t)ncells * 3, 0.0);
+    for (int64_t c = 0; c < ncells; ++c) {
+        const double *Ji = &M.jinv[(size_t)c * dim * dim];
+        const double *sg = &g->sigma[(size_t)c * dim];
+        for (int a = 0; a < dim; ++a) {
+            double s = 0.0;
+            for (int k = 0; k < dim; ++k) s += Ji[k + dim * a] * (sg[k] * xi[k]);
+            pv[(size_t)c * 3 + a] = -M.detj[c] * s;
+        }
+    }
+    return pv;
+}
+
+int hmg_integrate(hmg_grid *g, int mode, hmg_vec *v, hmg_vec *vprev, int64_t ncells_subset, const double *xi, double *out)
+{
+    HMG_TRY
+    need(g && g->has_op && v && out, "null argument or operator not set");
+    need(!g->part, "driver integrals on a partitioned grid are not supported yet");
+    check_vec(g, v->level, v, "v");
+    need(ncells_subset >= 0 && ncells_subset <= g->md.ncells, "subset out of range");
+    const MeshTables &M = g->cur();
+    const int dim = g->dim;
+    if (mode == 2) {   // integrate_area: sum(mass) * sum |J|   (ref: ...:673-689)
+        const double m_total = dim == 3 ? 1.0 / 6.0 : 0.5;
+        double area = 0.0;
+        for (int64_t c = 0; c < ncells_subset; ++c) area += m_total * M.detj[c];
+        *out = area;
+        return 0;
+    }
+    need(mode == 0 || mode == 1, "mode must be 0 (first term), 1 (terms) or 2 (area)");
+    if (ncells_subset == 0) {
+        *out = 0.0;
+        return 0;
+    }
+    DevBuf<double> d;
+    if (mode == 0) {
+        need(xi != nullptr, "xi required for the first term");
+        d.upload(axi_pvec(g, M, xi, ncells_subset), g->ctx->stream);
+    } else {
+        need(vprev != nullptr, "vprev required");
+        check_vec(g, v->level, vprev, "vprev");
+    }
+    launch_integrate(g->ctx->L, lev(g, v->level), g->md, mode, ncells_subset, v->d, vprev ? vprev->d : nullptr, d.p,
+                     S_TMP);
+    *out = read_scalar(g->ctx, S_TMP);
     HMG_END
 }
 

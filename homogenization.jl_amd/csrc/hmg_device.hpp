@@ -138,6 +138,10 @@ void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const
 // b[slot, cell] = dot(dphi[slot], pvec[cell])   (rhs_a xi grad v)
 void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const double *pvec, double *b);
 
+// scal[slot] = integral over the first nsub cells (mode 0: first term, needs pvec; mode 1: needs w2)
+void launch_integrate(const Launch &L, const LevelDev &lv, const MeshDev &mesh, int mode, int64_t nsub, const double *v,
+                      const double *w2, const double *pvec, int slot);
+
 // multi-GPU cut exchange: unpack = 0 packs buf[gid] <- x (first local copy), 1 writes x <- buf[gid]
 void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nentries, const int64_t *gid,
                      const int32_t *cell_lid, const uint8_t *first, double *buf, double *x, int unpack);

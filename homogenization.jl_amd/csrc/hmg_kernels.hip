@@ -1107,6 +1107,90 @@ void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// driver integrals over a prefix of cells (ref: src/examples/homogenized_coefficients.jl:592-667)
+//   mode 0: sum_cells |J| sum_i v_i (dphi_i . P_cell + (M v)_i)          integrate_first_term
+//   mode 1: sum_cells |J| sum_i (v_i + w_i) (M v)_i                      integrate_terms
+// M = reference-element mass matrix of the level (mass term of the class stencil, unscaled).
+// ---------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(256)
+k_integrate(LevelDev lv, const double *__restrict__ coef, int mode, const double *__restrict__ v,
+            const double *__restrict__ w2, const double *__restrict__ pvec, double *blockpart)
+{
+    constexpr int NDIR = DIM == 3 ? 15 : 7;
+    constexpr int NTERM = DIM == 3 ? 7 : 4;
+    constexpr int NT = 256;
+    extern __shared__ double smem[];
+    double *W = smem;
+    double *xs = smem + WSZ + lv.lds_g0;
+    const int tid = threadIdx.x;
+    const int64_t cell = blockIdx.x;
+    const int nf = lv.nf;
+    for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) W[idx] = lv.ctab[(size_t)idx * NTERM + NTERM - 1];
+    for (int q = tid; q < lv.lds_g0; q += NT) smem[WSZ + q] = 0.0;
+    for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
+    const double *vc = v + cell * lv.ld;
+    for (int t = tid; t < nf; t += NT) xs[lv.lpos[t]] = vc[t];
+    __syncthreads();
+    const double *wc = w2 ? w2 + cell * lv.ld : nullptr;
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
+    if (mode == 0) {
+        p0 = pvec[3 * cell];
+        p1 = pvec[3 * cell + 1];
+        p2 = pvec[3 * cell + 2];
+    }
+    double acc = 0.0;
+    for (int t = tid; t < nf; t += NT) {
+        int L, len, A, B, cls;
+        decode32<DIM>(lv.pos32[t], lv.m, L, len, A, B, cls);
+        const double *wr = W + cls * NDIR;
+        double w[NDIR];
+#pragma unroll
+        for (int d = 0; d < NDIR; ++d) w[d] = lds_ld(wr + d);
+        double ctr;
+        const double mv = stencil_eval_v<DIM>(w, xs + L, len, A, B, ctr);
+        if (mode == 0) {
+            const double *d = lv.dphi + 3 * t;
+            double dp = d[0] * p0;
+            dp += d[1] * p1;
+            if (DIM == 3) dp += d[2] * p2;
+            acc += ctr * (dp + mv);
+        } else
+            acc += (ctr + wc[t]) * mv;
+    }
+    __syncthreads();
+    const double s = block_sum(acc, smem);
+    if (tid == 0) {
+        blockpart[2 * cell] = s * coef[cell * 8 + NTERM - 1];   // times |J|
+        blockpart[2 * cell + 1] = 0.0;
+    }
+}
+
+void launch_integrate(const Launch &L, const LevelDev &lv, const MeshDev &mesh, int mode, int64_t nsub, const double *v,
+                      const double *w2, const double *pvec, int slot)
+{
+    const size_t lds = apply_lds_bytes(lv);
+    if (lds > 160 * 1024) throw std::runtime_error("integrals: cell does not fit LDS");
+    if (lv.dim == 3) {
+        auto k = k_integrate<3>;
+        if (lds > 48 * 1024)
+            HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)nsub), dim3(256), lds, L.stream, lv, mesh.coef, mode, v, w2, pvec,
+                           mesh.blockpart);
+    } else {
+        auto k = k_integrate<2>;
+        if (lds > 48 * 1024)
+            HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)nsub), dim3(256), lds, L.stream, lv, mesh.coef, mode, v, w2, pvec,
+                           mesh.blockpart);
+    }
+    check_launch();
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(256), dim3(256), 0, L.stream, mesh.blockpart, nsub, L.partials);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, 256, L.scal, slot);
+    check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // right-hand side F(v) = -int a xi . grad v  (ref: src/examples/homogenized_coefficients.jl:449-474)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

@@ -139,3 +139,85 @@ def checkerboard_problem(ctx, eltype, width: int, levels: int, seed: int = 0, va
     implicit = api.ImplicitFineGrid(ctx, base, levels)
     op = api.L2PlusDivAGrad(implicit, lam, cond)
     return base, cond, implicit, op
+
+
+def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, smoothing_steps: int = 3,
+                                tolerance: float = 1e-4, xi=None, save=None, *, ctx=None, seed: int = 0,
+                                values=(1.0, 9.0), sigma_grid=None, x0=None, max_cycles: int = 1000, log=None):
+    """checkerboard_homogenization(n, type; refinements, smoothing_steps, tolerance, xi, save) -> sigma
+    (src/examples/homogenized_coefficients.jl:174-343) with every level-vector operation on the device.
+
+    Differences to the reference, all explicit: the coefficient field and the initial guess are seeded
+    (`seed`, or passed in as `sigma_grid` / `x0`) instead of drawn from the global RNG; `save` (VTK export) is
+    not supported; the level-1 solve is the library's PCG; a domain shrink keeps the level vectors in place
+    (their columns are a prefix) instead of copying slices.  Returns (sigma, history) where history holds
+    (k, cycle, norm(r), sigma + dsigma, |dsigma - dsigma_prev|) -- the three quantities the reference logs."""
+    if save is not None:
+        raise NotImplementedError("VTK export (`save`) is outside the hot path")
+    dim = api._dim_of(eltype)
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = api.Context(0)
+    xi = random_unit_vec(dim) if xi is None else np.asarray(xi, dtype=np.float64)
+    lam, sigma = 1.0, 0.0
+    box_radius = compute_box_radius(0, n)
+    boundary_layer = compute_boundary_layer(lam, n)
+    total_radius = box_radius + boundary_layer
+    width = 2 * total_radius
+    base = order_nodes_and_elements_by_magnitude(hypercube(eltype, width, origin=(-float(total_radius),) * dim))
+    if sigma_grid is None:
+        sigma_grid = generate_conductivity(dim, width, seed, values)
+    cond = conductivity_per_element(base, sigma_grid, (total_radius + 1.0,) * dim)
+    total_grids = refinements + 1
+    implicit = api.ImplicitFineGrid(ctx, base, total_grids)
+    op = api.L2PlusDivAGrad(implicit, lam, cond)
+    ops = [op] * total_grids
+    states = [api.LevelState(implicit, i + 1) for i in range(total_grids)]
+    top = states[-1]
+    if x0 is None:
+        top.x.rand(seed + 1)
+    else:
+        top.x.from_host(x0)
+    api.broadcast_interfaces(top.x, implicit, total_grids)
+    api.apply_constraint(top.x, total_grids, implicit)
+    api.rhs_axi_grad_v(top.b, implicit, xi)
+    v_prev = api.DeviceMatrix(implicit, total_grids)
+    cur = base
+    history = []
+    for k in range(n + 1):
+        base_level = api.BaseLevel(implicit)             # level-1 operator for the current lam / domain
+        dsig, dsig_prev = 0.0, 0.0
+        for i in range(1, max_cycles + 1):
+            api.vcycle(implicit, base_level, ops, states, total_grids, smoothing_steps)
+            nint = find_elements_in_radius(cur, box_radius)
+            area = api.integrate_area(top.x, implicit, nint)
+            if k == 0:
+                integral = api.integrate_first_term(top.x, implicit, nint, xi)
+            else:
+                integral = api.integrate_terms(top.x, v_prev, implicit, nint)
+            dsig = 2.0 ** k * integral / area
+            rnorm = api.norm_unique(top.r)
+            history.append((k, i, rnorm, sigma + dsig, abs(dsig - dsig_prev)))
+            if log:
+                log(history[-1])
+            if abs(dsig - dsig_prev) < tolerance:
+                break
+            dsig_prev = dsig
+        sigma += dsig
+        lam /= 2
+        box_radius = compute_box_radius(k + 1, n)
+        boundary_layer = compute_boundary_layer(lam, n)
+        if box_radius + boundary_layer > total_radius:
+            break
+        total_radius = box_radius + boundary_layer
+        nn_keep = find_nodes_in_radius(cur, total_radius)
+        ne_keep = find_elements_in_radius(cur, total_radius)
+        cur = Mesh(cur.nodes[:nn_keep], np.ascontiguousarray(cur.elements[:ne_keep]))
+        implicit.shrink(ne_keep, nn_keep)                # new boundary; level vectors keep their storage
+        api.apply_constraint(top.x, total_grids, implicit)
+        v_prev.copyto(top.x)
+        op.lam = lam
+        api.next_rhs(top.b, top.x, implicit)
+    if own_ctx:
+        ctx.sync()
+    return sigma, history

@@ -298,3 +298,48 @@ def test_driver_right_hand_sides(case3):
     O.next_rhs(want2, x, c.impl, O.mass_matrix(c.impl.reference.levels[-1]), c.lam)
     hmg.next_rhs(b, c.dev(lev, x), c.g)
     assert relerr(b.to_host(), want2) <= 1e-12
+
+
+def test_driver_integrals(case3):
+    """integrate_first_term / integrate_terms / integrate_area -- ref: ...homogenized_coefficients.jl:592-689"""
+    c = case3
+    O = c.O
+    lev = c.levels
+    xi = np.array([0.2, -0.5, 0.84])
+    mass = O.mass_matrix(c.impl.reference.levels[-1])
+    dphis = O.partial_derivatives_functionals(c.impl.reference.levels[-1])
+    v, w = c.rand(lev), c.rand(lev)
+    dv, dw = c.dev(lev, v), c.dev(lev, w)
+    for nsub in (0, 7, c.mesh.nelements()):
+        a = O.integrate_first_term(v, dphis, c.impl, nsub, mass, c.sig, xi)
+        assert abs(hmg.integrate_first_term(dv, c.g, nsub, xi) - a) <= 1e-11 * max(abs(a), 1.0)
+        b = O.integrate_terms(v, w, c.impl, nsub, mass)
+        assert abs(hmg.integrate_terms(dv, dw, c.g, nsub) - b) <= 1e-11 * max(abs(b), 1.0)
+        ar = O.integrate_area(mass, c.impl, nsub)
+        assert abs(hmg.integrate_area(dv, c.g, nsub) - ar) <= 1e-12 * max(ar, 1.0)
+
+
+@pytest.mark.parametrize("dim,n,refinements,tol", [(2, 1, 2, 1e-4), (3, 0, 2, 1e-3)])
+def test_checkerboard_homogenization_matches_oracle_driver(oracle, ctx, dim, n, refinements, tol):
+    """The whole driver (outer shrink loop, V-cycles to tolerance, integrals, next rhs) on the device vs the
+    oracle's restatement of src/examples/homogenized_coefficients.jl:174-343, identical sigma field and x0.
+    |delta sigma| <= 1e-8, same number of V-cycles."""
+    from homogenization_jl_amd import driver
+    O = oracle
+    tag = hmg.Tet64 if dim == 3 else hmg.Tri64
+    lam = 1.0
+    width = 2 * (driver.compute_box_radius(0, n) + driver.compute_boundary_layer(lam, n))
+    sgrid = driver.generate_conductivity(dim, width, 11)
+    nf = {2: [3, 6, 15, 45], 3: [4, 10, 35, 165]}[dim][refinements]
+    ne = (2 if dim == 2 else 6) * width ** dim
+    x0 = hmg.host_random((nf, ne), 99)
+    want, hist_o = O.checkerboard_homogenization(n=n, dim=dim, refinements=refinements, tolerance=tol,
+                                                 sigma_grid=sgrid, x0=x0)
+    got, hist_d = driver.checkerboard_homogenization(n, tag, refinements=refinements, tolerance=tol, ctx=ctx,
+                                                     sigma_grid=sgrid, x0=x0)
+    assert len(hist_o) == len(hist_d)
+    assert abs(got - want) <= 1e-8
+    for a, b in zip(hist_o, hist_d):
+        assert a[:2] == b[:2]
+        assert abs(a[2] - b[2]) <= 1e-7 * max(a[2], 1e-12)          # residual norm per cycle
+        assert abs(a[3] - b[3]) <= 1e-8                              # sigma + dsigma per cycle
