@@ -15,6 +15,7 @@
 
 using namespace hmg;
 
+
 #define HIPCHK(expr)                                                                            \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \

@@ -548,16 +548,34 @@ k_restrict(LevelDev fine, int nfc, int ldc, const double *__restrict__ rf, doubl
     const double *f = rf + cell * fine.ld;
     const double *fs = f;
     if (USE_LDS) {
-        for (int t = threadIdx.x; t < fine.nf; t += NT) smem[t] = f[t];
+        constexpr int SPT = 8;   // loads first, LDS writes second: keeps 8 loads per thread in flight
+        for (int t0 = threadIdx.x; t0 < fine.nf; t0 += NT * SPT) {
+            double v[SPT];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = t0 + q * NT;
+                v[q] = t < fine.nf ? f[t] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = t0 + q * NT;
+                if (t < fine.nf) smem[t] = v[q];
+            }
+        }
         __syncthreads();
         fs = smem;
     }
     double *c = bc + cell * ldc;
     for (int t = threadIdx.x; t < nfc; t += NT) {
-        const int b = fine.rptr[t], e = fine.rptr[t + 1];
+        const int b = fine.rptr[t], n = fine.rptr[t + 1] - b;   // 1 <= n <= 15 (3D) / 7 (2D)
+        int idx[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) idx[q] = fine.ridx[b + (q < n ? q : 0)];   // all index loads in flight at once
         double tmp = 0.0;
-        tmp += 1.0 * fs[fine.ridx[b]];
-        for (int q = b + 1; q < e; ++q) tmp += 0.5 * fs[fine.ridx[q]];
+        tmp += 1.0 * fs[idx[0]];
+#pragma unroll
+        for (int q = 1; q < 15; ++q)
+            if (q < n) tmp += 0.5 * fs[idx[q]];
         c[t] = tmp;
     }
 }
@@ -586,6 +604,11 @@ void launch_restrict(const Launch &L, const LevelDev &fine, const LevelDev &coar
     if (fine.nf <= 256) {
         hipLaunchKernelGGL((k_restrict<64, true>), dim3((unsigned)ncells), dim3(64), lds, L.stream, fine, coarse.nf,
                            coarse.ld, rf, bc);
+    } else if (lds <= 160 * 1024 && fine.nf > 2048) {
+        auto k = k_restrict<1024, true>;
+        if (lds > 48 * 1024)
+            HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)ncells), dim3(1024), lds, L.stream, fine, coarse.nf, coarse.ld, rf, bc);
     } else if (lds <= 160 * 1024) {
         auto k = k_restrict<256, true>;
         if (lds > 48 * 1024)
