@@ -46,7 +46,7 @@ def cpu_baseline(sample_width, levels, steps_top):
     dphis = O.partial_derivatives_functionals(impl.reference.levels[-1])
     O.rhs_axi_grad_v(st[-1].b, dphis, impl, sig, np.ones(3) / np.sqrt(3.0))
     base = O.make_base_level(m, sig, 1.0)
-    threads = O.lib().orc_max_threads()
+    threads = O.available_cores()
     t0 = time.perf_counter()
     O.vcycle(impl, base, ops, st, levels, steps_top)
     dt = time.perf_counter() - t0

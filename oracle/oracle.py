@@ -765,11 +765,37 @@ def _geom(base: Mesh):
     return _GEOM_CACHE[key][1:]
 
 
-NTHREADS = [0]   # 0 -> all OpenMP threads
+NTHREADS = [0]   # 0 -> every core this process may use
+
+
+def available_cores():
+    """Cores this process can actually run on: scheduler affinity capped by the cgroup CPU quota
+    (omp_get_max_threads reports the host's hardware threads even inside a limited container)."""
+    n = lib().orc_max_threads()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / int(g.read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
 
 
 def _nthreads():
-    return NTHREADS[0] if NTHREADS[0] > 0 else lib().orc_max_threads()
+    return NTHREADS[0] if NTHREADS[0] > 0 else available_cores()
 
 
 def mul(alpha, base: Mesh, A, x, y):
