@@ -58,7 +58,9 @@ struct DevBuf {
 struct LevelBufs {
     DevBuf<uint64_t> meta;
     DevBuf<uint16_t> lpos, sweep_slot;
-    DevBuf<uint32_t> pos32, sweep32;
+    DevBuf<int> slab_k;
+    int nslab = 0, slab_lds_nodes = 0;
+    DevBuf<uint32_t> pos32, pos32w, sweep32;
     DevBuf<uint64_t> sweep_meta;
     DevBuf<double> ctab;
     DevBuf<int32_t> hier2slot, par_a, par_b, rptr, ridx;
@@ -241,27 +243,49 @@ static void upload_levels(hmg_grid *g)
                 B.lpos.upload(lp, s);
             }
             {
-                // compact addressing word: L | j<<16 | k<<22 | cls<<28  (len, A, B follow from j, k, m)
-                auto pack32 = [&](uint64_t mt, int cls) {
-                    uint32_t Lx = (uint32_t)(mt & 0xffffu), len = (uint32_t)((mt >> 16) & 0xffu);
-                    uint32_t A = (uint32_t)((mt >> 32) & 0xffffu);
-                    // recover j, k: len = m+1-j-k ; A = T_k - j (3D) ; 2D: k = 0
-                    uint32_t k = 0, j = 0;
-                    if (T.dim == 3) {
-                        for (k = 0; k <= (uint32_t)T.m; ++k) {
-                            uint32_t n = T.m - k, Tk = (n + 1) * (n + 2) / 2;
-                            j = T.m + 1 - k - len;
-                            if (Tk - j == A) break;
-                        }
-                    } else
-                        j = T.m + 1 - len;
-                    return Lx | (j << 16) | (k << 22) | ((uint32_t)cls << 28);
+                // compact / wide addressing words (decode32 / decode32w in hmg_kernels.hip)
+                std::vector<int32_t> slot_of_L(T.nf, -1);
+                for (int q = 0; q < T.nf; ++q) slot_of_L[(size_t)(T.meta[q] & 0xffffu)] = q;
+                const bool compact_ok = T.dim == 3 ? T.m <= 63 : T.m <= 255;
+                auto pack32 = [&](uint64_t mt, int cls) -> uint32_t {
+                    if (!compact_ok) return 0u;
+                    const int sl = slot_of_L[(size_t)(mt & 0xffffu)];
+                    const uint32_t j = T.slot_ijk[3 * sl + 1], k = T.slot_ijk[3 * sl + 2];
+                    return (uint32_t)(mt & 0xffffu) | (j << 16) | (T.dim == 3 ? (k << 22) : 0u) | ((uint32_t)cls << 28);
                 };
-                std::vector<uint32_t> p32(T.meta.size()), s32(T.sweep_meta.size());
-                for (size_t q = 0; q < p32.size(); ++q) p32[q] = pack32(T.meta[q], T.slot_cls[q]);
+                std::vector<uint32_t> p32(T.meta.size()), s32(T.sweep_meta.size()), p32w(T.meta.size());
+                for (size_t q = 0; q < p32.size(); ++q) {
+                    p32[q] = pack32(T.meta[q], T.slot_cls[q]);
+                    const uint32_t i = T.slot_ijk[3 * q], j = T.slot_ijk[3 * q + 1], k = T.slot_ijk[3 * q + 2];
+                    if (T.dim == 3 && (i > 127 || j > 127 || k > 127))
+                        throw std::runtime_error("lattice coordinate exceeds 127");
+                    p32w[q] = (i & 127u) | ((j & 127u) << 7) | ((k & 127u) << 14) | ((uint32_t)T.slot_cls[q] << 21);
+                }
                 for (size_t q = 0; q < s32.size(); ++q) s32[q] = pack32(T.sweep_meta[q], 0);
                 B.pos32.upload(p32, s);
+                B.pos32w.upload(p32w, s);
                 B.sweep32.upload(s32, s);
+            }
+            if (T.dim == 3 && sizeof(double) * (size_t)(232 + T.lds_g0 + T.nf + T.lds_g1) > 160 * 1024) {
+                // greedy slabs of k-planes: planes [k0-1, k1] (+ guards) must fit ~150 KiB of LDS
+                const int cap = (150 * 1024) / 8 - 232;
+                auto po = [&](int k) {
+                    long long n1 = T.m + 1, n2 = T.m + 1 - std::min(std::max(k, 0), T.m + 1);
+                    return (int)((n1 * (n1 + 1) * (n1 + 2) - n2 * (n2 + 1) * (n2 + 2)) / 6);
+                };
+                std::vector<int> sk{0};
+                int maxn = 0;
+                while (sk.back() <= T.m) {
+                    int k0 = sk.back(), k1 = k0 + 1;
+                    while (k1 <= T.m && T.lds_g0 + T.lds_g1 + po(k1 + 2) - po(k0 - 1) <= cap) ++k1;
+                    int nn = T.lds_g0 + T.lds_g1 + po(k1 + 1) - po(k0 - 1);
+                    if (nn > cap) throw std::runtime_error("apply slabs: a single plane does not fit the LDS");
+                    maxn = std::max(maxn, nn);
+                    sk.push_back(k1);
+                }
+                B.nslab = (int)sk.size() - 1;
+                B.slab_lds_nodes = maxn;
+                B.slab_k.upload(sk, s);
             }
             B.sweep_meta.upload(T.sweep_meta, s);
             B.sweep_slot.upload(T.sweep_slot, s);
@@ -299,6 +323,7 @@ static void upload_levels(hmg_grid *g)
         D.sweep_meta = B.sweep_meta.p;
         D.sweep_slot = B.sweep_slot.p;
         D.pos32 = B.pos32.p;
+        D.pos32w = B.pos32w.p;
         D.sweep32 = B.sweep32.p;
         D.nsweep = (int)T.sweep_meta.size();
         D.ctab = B.ctab.p;
@@ -331,6 +356,14 @@ void upload_operator(hmg_grid *g)
 
 void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);   // defined below
 
+void set_slab(hmg_grid *g, const LevelDev &lv)
+{
+    const LevelBufs &B = *g->lb[lv.level - 1];
+    g->md.slab_k = B.slab_k.p;
+    g->md.nslab = B.nslab;
+    g->md.slab_lds_nodes = B.slab_lds_nodes;
+}
+
 // every operator apply goes through here: optional HIP-event bracketing for bench.py's roofline
 void apply(hmg_grid *g, const LevelDev &lv, double alpha, const double *x, const double *src, double *out, int mask)
 {
@@ -346,6 +379,7 @@ void apply(hmg_grid *g, const LevelDev &lv, double alpha, const double *x, const
         }
         HIPCHK(hipEventRecord(t.pool[t.used].first, c->stream));
     }
+    set_slab(g, lv);
     launch_apply(c->L, lv, g->md, alpha, g->lambda, x, src, out, mask);
     if (timed) {
         HIPCHK(hipEventRecord(t.pool[t.used].second, c->stream));
@@ -414,7 +448,7 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
     apply(g, lv, -1.0, x->d, b->d, r->d, 1);                            // r = b - A x, constraint
     interface_sum(g, lv, r->d);
     int cur = S_RS, other = S_RS2;
-    if (g->fuse_cg) {
+    if (g->fuse_cg && apply_lds_bytes(lv) <= 160 * 1024) {
         // p-update and both reductions ride along with the operator apply (see k_apply<.., FUSED>)
         for (int i = 0; i < steps; ++i) {
             if (i == 0) {
@@ -1320,6 +1354,7 @@ int hmg_next_rhs(hmg_grid *g, hmg_vec *x, hmg_vec *b)
     need(x->d != b->d, "x and b must not alias");
     // b = lambda*|J|*M*x  (ref: ...homogenized_coefficients.jl:695-713)
     g->ctx->L.apply_mass_only = 1;
+    set_slab(g, lev(g, x->level));
     try {
         launch_apply(g->ctx->L, lev(g, x->level), g->md, 1.0, g->lambda, x->d, nullptr, b->d, 0);
     } catch (...) {

@@ -20,7 +20,8 @@ struct LevelDev {
     const uint64_t *sweep_meta;    // [nsweep] interior sweep (lattice order, idle lanes on surface ends)
     const uint16_t *sweep_slot;    // [nsweep] storage slot or 0xffff
     int nsweep;
-    const uint32_t *pos32;         // [nf]     L | j<<16 | k<<22 | cls<<28
+    const uint32_t *pos32;         // [nf]     L | j<<16 | k<<22 | cls<<28 (levels whose cell fits the LDS)
+    const uint32_t *pos32w;        // [nf]     i | j<<7 | k<<14 | cls<<21  (3D, any level)
     const uint32_t *sweep32;       // [nsweep] same packing, cls = 0
     const double *ctab;            // [ncls*ndir*nterm]
     const int32_t *hier2slot;      // [nf]
@@ -44,6 +45,9 @@ struct MeshDev {
     const double *coef;          // 8 per cell
     const uint8_t *mult;         // 16 per cell: number of copies of each entity (bit order of the masks)
     double *blockpart;           // 2 per cell: scratch for the fused apply's block sums
+    // slab decomposition of the finest level when one cell exceeds the LDS (set per launch by the host)
+    const int *slab_k;           // nslab + 1 plane boundaries
+    int nslab, slab_lds_nodes;
 };
 
 struct ApplyArgs {

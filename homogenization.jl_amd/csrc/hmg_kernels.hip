@@ -146,22 +146,42 @@ __device__ __forceinline__ double to_sgpr(double v)
     return __hiloint2double((int)hi, (int)lo);
 }
 
+// Compact addressing word of the LDS-resident kernels: L | j<<16 | k<<22 | cls<<28 in 3D (j, k <= 63, i.e.
+// levels whose cell fits the LDS), L | j<<16 | cls<<28 in 2D (j <= 255).  Rows have len = m+1-j-k nodes;
+// A / B are the address offsets to the same (i,j) in the planes above / below.
 template <int DIM>
 __device__ __forceinline__ void decode32(uint32_t w, int m, int &L, int &len, int &A, int &B, int &cls)
 {
     L = (int)(w & 0xffffu);
-    const int j = (int)((w >> 16) & 63u), k = (int)((w >> 22) & 63u);
     cls = (int)(w >> 28);
-    len = m + 1 - j - k;
     if (DIM == 3) {
+        const int j = (int)((w >> 16) & 63u), k = (int)((w >> 22) & 63u);
+        len = m + 1 - j - k;
         const int n = m - k;
         const int Tk = ((n + 1) * (n + 2)) >> 1;
         A = Tk - j;
         B = Tk + n + 2 - j;
     } else {
+        const int j = (int)((w >> 16) & 255u);
+        len = m + 1 - j;
         A = 0;
         B = 0;
     }
+}
+
+// Wide word of the slab kernel (cells larger than the LDS): i | j<<7 | k<<14 | cls<<21, L recomputed.
+__device__ __forceinline__ void decode32w(uint32_t w, int m, int &L, int &len, int &A, int &B, int &cls, int &k)
+{
+    const int i = (int)(w & 127u), j = (int)((w >> 7) & 127u);
+    k = (int)((w >> 14) & 127u);
+    cls = (int)(w >> 21);
+    len = m + 1 - j - k;
+    const int n = m - k;
+    const int Tk = ((n + 1) * (n + 2)) >> 1;
+    A = Tk - j;
+    B = Tk + n + 2 - j;
+    const int full = (m + 1) * (m + 2) * (m + 3), rest = (n + 1) * (n + 2) * (n + 3);
+    L = (full - rest) / 6 + j * (n + 1) - ((j * (j - 1)) >> 1) + i;
 }
 
 // One workgroup per coarse cell.  Load phase: coalesced column read, scatter into the LDS lattice
@@ -315,6 +335,72 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     }
 }
 
+// Slab variant for cells whose lattice image exceeds the LDS (level 7 in 3D: 374 KiB): the cell is
+// processed in slabs of consecutive k-planes; the LDS holds planes [k0-1, k1] of the lattice image, nodes of
+// planes [k0, k1) are evaluated.  Same tables, same arithmetic as k_apply; not fused, not tuned.
+template <int DIM, int NT>
+__global__ void __launch_bounds__(NT)
+k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a,
+             const int *__restrict__ slab_k, int nslab, int lds_nodes)
+{
+    constexpr int NDIR = DIM == 3 ? 15 : 7;
+    constexpr int NTERM = DIM == 3 ? 7 : 4;
+    extern __shared__ double smem[];
+    double *W = smem;
+    double *img = smem + WSZ;                       // lds_nodes doubles: [guard g0 | planes k0-1..k1 | guard g1]
+    const int tid = threadIdx.x;
+    const int64_t cell = blockIdx.x;
+    const int nf = lv.nf, m = lv.m;
+
+    double s[NTERM];
+    cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
+    for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
+        const double *c = lv.ctab + (size_t)idx * NTERM;
+        double w = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
+        W[idx] = w;
+    }
+    const double *xc = a.x + cell * lv.ld;
+    const uint32_t dm = (a.flags & 1) ? dmask[cell] : 0u;
+    const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
+    double *oc = a.out + cell * lv.ld;
+    auto plane_off = [&](int k) {   // PO(k) = number of lattice nodes in planes < k (3D), 0 in 2D
+        if (DIM != 3) return 0;
+        if (k <= 0) return 0;
+        if (k > m + 1) k = m + 1;
+        // sum_{q<k} (m-q+1)(m-q+2)/2 = T(m+1) - T(m+1-k), T(n) = n(n+1)(n+2)/6
+        const long long n1 = m + 1, n2 = m + 1 - k;
+        return (int)((n1 * (n1 + 1) * (n1 + 2) - n2 * (n2 + 1) * (n2 + 2)) / 6);
+    };
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int k0 = slab_k[sl], k1 = slab_k[sl + 1];
+        const int lo = plane_off(k0 - 1), hi = plane_off(k1 + 1);   // lattice range held in LDS: [lo, hi)
+        double *xs = img + lv.lds_g0 - lo;                          // xs[L] valid for lo - g0 <= L < hi + g1
+        __syncthreads();                                            // previous slab fully consumed
+        for (int q = tid; q < lds_nodes; q += NT) img[q] = 0.0;
+        __syncthreads();
+        for (int t = tid; t < nf; t += NT) {
+            const int L = lv.lpos[t];
+            if (L >= lo && L < hi) xs[L] = xc[t];
+        }
+        __syncthreads();
+        for (int t = tid; t < nf; t += NT) {
+            int L, len, A, B, cls, k;
+            decode32w(lv.pos32w[t], m, L, len, A, B, cls, k);
+            if (k < k0 || k >= k1) continue;
+            const double *wr = W + cls * NDIR;
+            double w[NDIR];
+#pragma unroll
+            for (int d = 0; d < NDIR; ++d) w[d] = lds_ld(wr + d);
+            double ctr;
+            double o = (sc ? sc[t] : 0.0) + stencil_eval_v<DIM>(w, xs + L, len, A, B, ctr);
+            if (cls > 0 && ((dm >> (cls - 1)) & 1u)) o = 0.0;
+            oc[t] = o;
+        }
+    }
+}
+
 // blockpart[2*c + {0,1}] -> partials[b], partials[2048 + b]  (256 blocks, fixed order: deterministic)
 __global__ void __launch_bounds__(256)
 k_reduce_pairs(const double *__restrict__ blockpart, int64_t n, double *partials)
@@ -352,9 +438,17 @@ template <int DIM, bool FUSED>
 static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a)
 {
     const size_t lds = apply_lds_bytes(lv);
-    if (lds > 160 * 1024)
-        throw std::runtime_error("operator apply: a cell of level " + std::to_string(lv.level) +
-                                 " does not fit the 160 KiB LDS (sub-blocked variant not built yet)");
+    if (lds > 160 * 1024) {
+        if (FUSED) throw std::runtime_error("fused CG pass is not available for cells larger than the LDS");
+        if (DIM != 3 || !mesh.slab_k) throw std::runtime_error("operator apply: cell does not fit the LDS");
+        auto kern = k_apply_slab<DIM, 1024>;
+        const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab_lds_nodes);
+        HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
+                           mesh.slab_k, mesh.nslab, mesh.slab_lds_nodes);
+        check_launch();
+        return;
+    }
     const int nf = lv.nf;
     int nt = L.apply_threads;
     if (nt == 0) nt = nf <= 64 ? 64 : nf <= 2048 ? 256 : 1024;

@@ -104,7 +104,9 @@ int dir_index(int dim, int di, int dj, int dk)
 std::vector<LevelTables> build_level_tables(int dim, int nlevels)
 {
     if (dim != 2 && dim != 3) throw std::runtime_error("dim must be 2 or 3");
-    if (nlevels < 1 || nlevels > 9) throw std::runtime_error("nlevels must be in 1..9");
+    // 16-bit lattice addresses and 6/8-bit row indices in the packed tables: m <= 64 (3D), m <= 128 (2D)
+    if (nlevels < 1 || nlevels > (dim == 3 ? 7 : 8))
+        throw std::runtime_error(dim == 3 ? "nlevels must be in 1..7 for tetrahedra" : "nlevels must be in 1..8 for triangles");
     const int ndir = dim == 3 ? 15 : 7;
     const int ndiff = dim == 3 ? 6 : 3;
     const int nterm = ndiff + 1;

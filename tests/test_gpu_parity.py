@@ -343,3 +343,31 @@ def test_checkerboard_homogenization_matches_oracle_driver(oracle, ctx, dim, n, 
         assert a[:2] == b[:2]
         assert abs(a[2] - b[2]) <= 1e-7 * max(a[2], 1e-12)          # residual norm per cycle
         assert abs(a[3] - b[3]) <= 1e-8                              # sigma + dsigma per cycle
+
+
+def test_level7_cells_larger_than_lds(oracle, ctx):
+    """refinements = 6: Nf = 47 905 (374 KiB per cell) does not fit the 160 KiB LDS; the slab-wise apply and the
+    unfused smoother take over.  ref: src/apply_local_operators.jl:85-133, src/multigrid.jl:46-71"""
+    O = oracle
+    c = Case(O, ctx, 3, 1, 7, lam=0.9, perturb=0.1, seed=13, ordered=False)
+    lev = 7
+    x, y = c.rand(lev), c.rand(lev)
+    want = y.copy(order="F")
+    O.mul(0.7, c.mesh, c.ops[lev - 1], x, want)
+    dx, dy = c.dev(lev, x), c.dev(lev, y)
+    hmg.mul(0.7, c.g, c.A, dx, dy)
+    assert relerr(dy.to_host(), want) <= TOL
+    st = _oracle_state(c, lev)
+    dst = hmg.LevelState(c.g, lev)
+    dst.x.from_host(st.x); dst.b.from_host(st.b)
+    O.smoothing_steps(2, c.impl, c.ops[lev - 1], st, lev)
+    hmg.smoothing_steps(2, c.g, c.A, dst, lev)
+    assert relerr(dst.x.to_host(), st.x) <= 1e-10
+    assert relerr(dst.r.to_host(), st.r) <= 1e-10
+    # transfer to / from level 6
+    P = c.impl.reference.interops[lev - 2]
+    wantb = np.zeros((c.impl.nf(lev - 1), c.mesh.nelements()), order="F")
+    O.restrict_to(wantb, P, st.r)
+    db = hmg.DeviceMatrix(c.g, lev - 1)
+    hmg.restrict_to(db, c.g, dst.r)
+    assert relerr(db.to_host(), wantb) <= 1e-10
