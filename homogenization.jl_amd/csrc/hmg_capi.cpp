@@ -269,6 +269,7 @@ static void upload_levels(hmg_grid *g)
             if (T.dim == 3 && sizeof(double) * (size_t)(232 + T.lds_g0 + T.nf + T.lds_g1) > 160 * 1024) {
                 // greedy slabs of k-planes: planes [k0-1, k1] (+ guards) must fit ~150 KiB of LDS
                 const int cap = (150 * 1024) / 8 - 232;
+                const int slab_g0 = ((T.m + 2) * (T.m + 3)) / 2 + 2;
                 auto po = [&](int k) {
                     long long n1 = T.m + 1, n2 = T.m + 1 - std::min(std::max(k, 0), T.m + 1);
                     return (int)((n1 * (n1 + 1) * (n1 + 2) - n2 * (n2 + 1) * (n2 + 2)) / 6);
@@ -277,8 +278,8 @@ static void upload_levels(hmg_grid *g)
                 int maxn = 0;
                 while (sk.back() <= T.m) {
                     int k0 = sk.back(), k1 = k0 + 1;
-                    while (k1 <= T.m && T.lds_g0 + T.lds_g1 + po(k1 + 2) - po(k0 - 1) <= cap) ++k1;
-                    int nn = T.lds_g0 + T.lds_g1 + po(k1 + 1) - po(k0 - 1);
+                    while (k1 <= T.m && slab_g0 + T.lds_g1 + po(k1 + 2) - po(k0 - 1) <= cap) ++k1;
+                    int nn = slab_g0 + T.lds_g1 + po(k1 + 1) - po(k0 - 1);
                     if (nn > cap) throw std::runtime_error("apply slabs: a single plane does not fit the LDS");
                     maxn = std::max(maxn, nn);
                     sk.push_back(k1);

@@ -139,6 +139,33 @@ __device__ __forceinline__ double stencil_eval_v(const double *w, const double *
     return acc;
 }
 
+// surface nodes: zero-weight taps may address below the lattice image (plane -1 / row -1): clamp to 0
+template <int DIM>
+__device__ __forceinline__ double stencil_eval_c(const double *w, const double *base, int L, int len, int A, int B,
+                                                 double &ctr)
+{
+    auto at = [&](int off) { return lds_ld(base + max(L + off, 0)); };
+    ctr = lds_ld(base + L);
+    double acc = w[0] * ctr;
+    acc += w[1] * lds_ld(base + L + 1);
+    acc += w[2] * at(-1);
+    acc += w[3] * lds_ld(base + L + len - 1);
+    acc += w[4] * at(-len);
+    acc += w[5] * lds_ld(base + L + len);
+    acc += w[6] * at(-len - 1);
+    if (DIM == 3) {
+        acc += w[7] * lds_ld(base + L + A - len);
+        acc += w[8] * at(len + 1 - B);
+        acc += w[9] * lds_ld(base + L + A - 1);
+        acc += w[10] * at(1 - B);
+        acc += w[11] * lds_ld(base + L + A);
+        acc += w[12] * at(-B);
+        acc += w[13] * lds_ld(base + L + A + 1 - len);
+        acc += w[14] * at(len - B);
+    }
+    return acc;
+}
+
 __device__ __forceinline__ double to_sgpr(double v)
 {
     const unsigned lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -192,7 +219,7 @@ __device__ __forceinline__ void decode32w(uint32_t w, int m, int &L, int &len, i
 //   epilogue     block sum of mult*xin*out  == this cell's share of dot(p, interface_sum(A p)), because
 //                p is identical in all copies of a shared DOF (src/multigrid.jl:54-68)
 template <int DIM, int NT, int SPT, bool FUSED>
-__global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 1)   // 2 x 1024 threads per CU need <= 64 VGPRs
+__global__ void __launch_bounds__(NT, NT >= 640 ? 8 : 1)   // 2 x 1024 / 3 x 640 threads per CU need <= 64 VGPRs
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
     constexpr int NDIR = DIM == 3 ? 15 : 7;
@@ -293,7 +320,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
 #pragma unroll
         for (int d = 0; d < NDIR; ++d) w[d] = lds_ld(wr + d);
         double ctr;
-        double o = sv + stencil_eval_v<DIM>(w, xs + L, len, A, B, ctr);
+        double o = sv + stencil_eval_c<DIM>(w, xs, L, len, A, B, ctr);
         if ((dm >> (cls - 1)) & 1u) o = 0.0;
         oc[t] = o;
         if (FUSED) {
@@ -351,6 +378,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     const int tid = threadIdx.x;
     const int64_t cell = blockIdx.x;
     const int nf = lv.nf, m = lv.m;
+    const int slab_g0 = ((m + 2) * (m + 3)) / 2 + 2;   // reach of the plane-below taps of plane-0 nodes
 
     double s[NTERM];
     cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
@@ -376,7 +404,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     for (int sl = 0; sl < nslab; ++sl) {
         const int k0 = slab_k[sl], k1 = slab_k[sl + 1];
         const int lo = plane_off(k0 - 1), hi = plane_off(k1 + 1);   // lattice range held in LDS: [lo, hi)
-        double *xs = img + lv.lds_g0 - lo;                          // xs[L] valid for lo - g0 <= L < hi + g1
+        double *xs = img + slab_g0 - lo;                            // xs[L] valid for lo - slab_g0 <= L < hi + g1
         __syncthreads();                                            // previous slab fully consumed
         for (int q = tid; q < lds_nodes; q += NT) img[q] = 0.0;
         __syncthreads();
@@ -460,6 +488,8 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         launch_apply_generic<DIM, 256, 8, FUSED>(L, lv, mesh, a, lds);
     else if (nt <= 512)
         launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
+    else if (nt <= 640)
+        launch_apply_generic<DIM, 640, 11, FUSED>(L, lv, mesh, a, lds);
     else
         launch_apply_generic<DIM, 1024, 7, FUSED>(L, lv, mesh, a, lds);
 }
@@ -1265,7 +1295,7 @@ k_integrate(LevelDev lv, const double *__restrict__ coef, int mode, const double
 #pragma unroll
         for (int d = 0; d < NDIR; ++d) w[d] = lds_ld(wr + d);
         double ctr;
-        const double mv = stencil_eval_v<DIM>(w, xs + L, len, A, B, ctr);
+        const double mv = stencil_eval_c<DIM>(w, xs, L, len, A, B, ctr);
         if (mode == 0) {
             const double *d = lv.dphi + 3 * t;
             double dp = d[0] * p0;

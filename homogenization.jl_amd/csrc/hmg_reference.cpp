@@ -284,7 +284,7 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
             return PO[k] + j * (n + 1) - j * (j - 1) / 2 + i;
         };
         T.meta.assign(nf, 0);
-        int amin = 0, amax = nf - 1;
+        int amin = 0, amax = nf - 1, amin_interior = 0;
         for (int s = 0; s < nf; ++s) {
             int i = T.slot_ijk[3 * s], j = T.slot_ijk[3 * s + 1], k = T.slot_ijk[3 * s + 2];
             int L = lin(i, j, k);
@@ -305,10 +305,15 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
                     throw std::runtime_error("reference lattice: neighbour addressing mismatch");
                 amin = std::min(amin, addr[d]);
                 amax = std::max(amax, addr[d]);
+                if (T.slot_cls[s] == 0) amin_interior = std::min(amin_interior, addr[d]);
             }
         }
-        T.lds_g0 = -amin;
+        // Addresses below 0 only occur for zero-weight taps of surface nodes (plane k = 0, row j = 0); the
+        // kernels clamp those to 0 instead of paying a front guard zone of ~T(m+2) doubles of LDS per cell.
+        if (amin_interior < 0) throw std::runtime_error("reference lattice: an interior node addresses below 0");
+        T.lds_g0 = 0;
         T.lds_g1 = amax - (nf - 1);
+        (void)amin;
 
         // interior sweep: rows (j,k) that contain cell-interior nodes, all positions i = 0..len-1
         T.sweep_meta.clear();
