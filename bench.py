@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--width", type=int, default=32, help="unit cubes per axis per GPU")
     ap.add_argument("--levels", type=int, default=6, help="refinements + 1")
     ap.add_argument("--smoothing-steps", type=int, default=3)
-    ap.add_argument("--cpu-sample-width", type=int, default=6)
+    ap.add_argument("--cpu-sample-width", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--apply-variant", type=int, default=None)
     ap.add_argument("--apply-threads", type=int, default=None)

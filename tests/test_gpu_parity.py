@@ -371,3 +371,40 @@ def test_level7_cells_larger_than_lds(oracle, ctx):
     db = hmg.DeviceMatrix(c.g, lev - 1)
     hmg.restrict_to(db, c.g, dst.r)
     assert relerr(db.to_host(), wantb) <= 1e-10
+
+
+def test_single_cell_and_all_dirichlet(oracle, ctx):
+    """Edge case: one tetrahedron.  No interfaces, the whole surface is Dirichlet, the level-1 system is empty
+    (x1 = 0); apply / smoother / V-cycle must still agree with the oracle."""
+    O = oracle
+    nodes = np.array([(0, 0, 0), (1, 0, 0), (0.2, 1, 0), (0.1, 0.3, 1)], dtype=np.float64)
+    m = O.Mesh(nodes, np.array([[0, 1, 2, 3]], dtype=np.int64))
+    levels = 5
+    sig = np.array([[1.0, 9.0, 9.0]])
+    impl = O.ImplicitFineGrid.create(m, levels)
+    cons = O.ZeroDirichletConstraint(*O.list_boundary_nodes_edges_faces(m))
+    ops = [O.L2PlusDivAGrad(O.build_local_diffusion_operators(l), O.mass_matrix(l), cons, 0.5, sig)
+           for l in impl.reference.levels]
+    g = hmg.ImplicitFineGrid(ctx, hmg.Mesh(m.nodes, m.elements + 1), levels)
+    A = hmg.L2PlusDivAGrad(g, 0.5, sig)
+    rng = np.random.default_rng(0)
+    sts = [O.LevelState.create(1, impl.nf(i + 1)) for i in range(levels)]
+    sts[-1].x[...] = rng.random(sts[-1].x.shape); sts[-1].b[...] = rng.standard_normal(sts[-1].x.shape)
+    O.apply_constraint(sts[-1].x, levels, cons, impl)
+    dsts = [hmg.LevelState(g, i + 1) for i in range(levels)]
+    dsts[-1].x.from_host(sts[-1].x); dsts[-1].b.from_host(sts[-1].b)
+    before = dsts[-1].x.to_host()
+    hmg.broadcast_interfaces(dsts[-1].x, g, levels)
+    np.testing.assert_array_equal(dsts[-1].x.to_host(), before)          # nothing shared: a no-op
+    assert O.list_interior_nodes(m).size == 0
+    # (A V-cycle is not defined here even in the reference: on levels 2-3 every DOF is Dirichlet, r = 0 and the
+    #  CG step divides 0/0.)  The finest level has interior DOFs: the smoother must agree.
+    O.smoothing_steps(3, impl, ops[-1], sts[-1], levels)
+    hmg.smoothing_steps(3, g, A, dsts[-1], levels)
+    assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-10
+    for lev in range(1, levels + 1):
+        x = np.asfortranarray(rng.standard_normal((impl.nf(lev), 1)))
+        want = np.zeros_like(x, order="F"); O.mul(1.0, m, ops[lev - 1], x, want)
+        dy = hmg.DeviceMatrix(g, lev).fill(0.0)
+        hmg.mul(1.0, g, A, hmg.DeviceMatrix(g, lev).from_host(x), dy)
+        assert relerr(dy.to_host(), want) <= TOL

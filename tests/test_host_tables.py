@@ -282,3 +282,31 @@ def test_driver_mesh_matches_reference_generator(oracle, dim, n):
     for lam, nn in ((1.0, 2), (0.5, 3), (0.25, 1)):
         assert driver.compute_boundary_layer(lam, nn) == O.compute_boundary_layer(lam, nn)
         assert driver.compute_box_radius(2, nn) == O.compute_box_radius(2, nn)
+
+
+def test_input_validation_reports_errors():
+    """Bad meshes are refused with a message (status code + hmg_last_error), never a crash."""
+    nodes = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)], dtype=np.float64)
+    with pytest.raises(hmg._lib.HmgError, match="ascending"):
+        hmg.ImplicitFineGrid(None, hmg.Mesh(nodes, np.array([[2, 1, 3, 4]])), 2)
+    with pytest.raises(hmg._lib.HmgError, match="out of range"):
+        hmg.ImplicitFineGrid(None, hmg.Mesh(nodes, np.array([[1, 2, 3, 5]])), 2)
+    with pytest.raises(hmg._lib.HmgError, match="degenerate"):
+        flat = nodes.copy(); flat[3] = (1, 1, 0)
+        hmg.ImplicitFineGrid(None, hmg.Mesh(flat, np.array([[1, 2, 3, 4]])), 2)
+    with pytest.raises(hmg._lib.HmgError, match="nlevels"):
+        hmg.ImplicitFineGrid(None, hmg.Mesh(nodes, np.array([[1, 2, 3, 4]])), 8)
+    g = hmg.ImplicitFineGrid(None, hmg.Mesh(nodes, np.array([[1, 2, 3, 4]])), 3)
+    with pytest.raises(hmg._lib.HmgError, match="no compute path|without a device"):
+        hmg.DeviceMatrix(g, 2)                              # host-only grid: no vectors, no compute
+
+
+def test_single_cell_mesh_tables():
+    """One tetrahedron: nothing is shared, everything on the surface is Dirichlet, no interior base node."""
+    nodes = np.array([(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)], dtype=np.float64)
+    g = hmg.ImplicitFineGrid(None, hmg.Mesh(nodes, np.array([[1, 2, 3, 4]])), 4)
+    assert g.table_i32("face_pairs").size == 0
+    assert list(g.table_i32("edge_ptr")) == [0] and list(g.table_i32("node_ptr")) == [0]
+    assert g.table_i32("dmask")[0] == (1 << 14) - 1 and g.table_i32("dupmask")[0] == 0
+    assert g.interior_nodes().size == 0
+    assert set(g.table_i32("mult")[:14]) == {1}
