@@ -67,7 +67,6 @@ def main():
     ap.add_argument("--smoothing-steps", type=int, default=3)
     ap.add_argument("--cpu-sample-width", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--apply-variant", type=int, default=None)
     ap.add_argument("--apply-threads", type=int, default=None)
     args = ap.parse_args()
 
@@ -98,8 +97,6 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = hmg.Context(local_rank, stream=stream)
-    if args.apply_variant is not None:
-        ctx.set_option("apply_variant", args.apply_variant)
     if args.apply_threads is not None:
         ctx.set_option("apply_threads", args.apply_threads)
 

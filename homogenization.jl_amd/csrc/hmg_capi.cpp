@@ -61,7 +61,6 @@ struct LevelBufs {
     DevBuf<int> slab_k;
     int nslab = 0, slab_lds_nodes = 0;
     DevBuf<uint32_t> pos32, pos32w, sweep32;
-    DevBuf<uint64_t> sweep_meta;
     DevBuf<double> ctab;
     DevBuf<int32_t> hier2slot, par_a, par_b, rptr, ridx;
     DevBuf<double> dphi;
@@ -288,7 +287,6 @@ static void upload_levels(hmg_grid *g)
                 B.slab_lds_nodes = maxn;
                 B.slab_k.upload(sk, s);
             }
-            B.sweep_meta.upload(T.sweep_meta, s);
             B.sweep_slot.upload(T.sweep_slot, s);
             B.ctab.upload(T.ctab, s);
             B.hier2slot.upload(T.hier2slot, s);
@@ -321,7 +319,6 @@ static void upload_levels(hmg_grid *g)
         D.nf_coarse = l > 0 ? g->lt[l - 1].nf : 0;
         D.meta = B.meta.p;
         D.lpos = B.lpos.p;
-        D.sweep_meta = B.sweep_meta.p;
         D.sweep_slot = B.sweep_slot.p;
         D.pos32 = B.pos32.p;
         D.pos32w = B.pos32w.p;
@@ -440,7 +437,10 @@ void apply_fused(hmg_grid *g, const LevelDev &lv, const double *r, const double 
     }
 }
 
-void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap)
+// keep_p = false skips the reference's last p-update (src/multigrid.jl:68) when its result is dead: inside a
+// V-cycle the pre-smoother's p is overwritten by the post-smoother's `p = r` before anyone can read it.
+void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
+            bool keep_p = true)
 {
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
@@ -463,8 +463,9 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
             scalar_sum(g, other, 1);
             std::swap(cur, other);
         }
-        if (steps > 0)
-            launch_cg_pupdate(L, p->d, r->d, n, cur, other);            // the reference's last p-update
+        if (steps > 0) {
+            if (keep_p) launch_cg_pupdate(L, p->d, r->d, n, cur, other);   // the reference's last p-update
+        }
         else {
             launch_copy_dot(L, p->d, r->d, n, cur);
             scalar_sum(g, cur, 1);
@@ -586,7 +587,7 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     }
     hmg_vec **nxt = st + 5 * (k - 2);
     const Launch &L = g->ctx->L;
-    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4]);
+    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*keep_p=*/steps == 0);
     apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                            // local residual
     launch_restrict(L, lev(g, k), lev(g, k - 1), g->md.ncells, cur[2]->d, nxt[1]->d);
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
@@ -675,7 +676,6 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.partials = c->partials.p;
     c->L.scal = c->scal.p;
     c->L.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->L.apply_variant = 0;
     c->L.apply_threads = 0;
     c->L.apply_mass_only = 0;
     *out = c.release();
@@ -706,9 +706,7 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
     HMG_TRY
     need(ctx && name, "null argument");
     std::string n(name);
-    if (n == "apply_variant")
-        ctx->L.apply_variant = (int)value;
-    else if (n == "apply_threads")
+    if (n == "apply_threads")
         ctx->L.apply_threads = (int)value;
     else if (n == "coarse_maxit")
         ctx->coarse_maxit = (int)value;

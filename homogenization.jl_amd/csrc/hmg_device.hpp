@@ -17,8 +17,8 @@ struct LevelDev {
     int nf_coarse;                 // nf of level-1 (0 on level 1)
     const uint64_t *meta;          // [nf]
     const uint16_t *lpos;          // [nf] LDS lattice index of every storage slot
-    const uint64_t *sweep_meta;    // [nsweep] interior sweep (lattice order, idle lanes on surface ends)
-    const uint16_t *sweep_slot;    // [nsweep] storage slot or 0xffff
+    const uint16_t *sweep_slot;    // [nsweep] interior sweep in LDS lattice order: storage slot, or 0xffff for
+                                   //          the two surface end positions of a row (idle lanes)
     int nsweep;
     const uint32_t *pos32;         // [nf]     L | j<<16 | k<<22 | cls<<28 (levels whose cell fits the LDS)
     const uint32_t *pos32w;        // [nf]     i | j<<7 | k<<14 | cls<<21  (3D, any level)
@@ -79,7 +79,6 @@ struct Launch {
     double *partials;     // >= 4096 doubles
     double *scal;         // S_COUNT doubles
     int num_cu;
-    int apply_variant;    // 0 generic, 1 persistent register-meta
     int apply_threads;    // 0 = auto
     int apply_mass_only;  // 1: only the mass term (next_rhs!), set around a single launch
 };

@@ -3,7 +3,8 @@
 // a Jacobi-PCG for the coarse system.  Wave = 64 lanes everywhere.
 //
 // Reference behaviour reproduced (file:line in the reference checkout):
-//   k_apply*            src/apply_local_operators.jl:85-133 (+ :7-27 residual, + constraint mask)
+//   k_apply, k_apply_slab  src/apply_local_operators.jl:85-133 (+ :7-27 residual, + constraint mask,
+//                          + the p-update and dot products of src/multigrid.jl:54-68 when FUSED)
 //   k_iface_*           src/implicit_fine_grid.jl:209-328   (copies summed in ascending cell order)
 //   k_mask              src/implicit_fine_grid.jl:94-139 / :334-386
 //   k_restrict/prolong  src/interpolation.jl:52-74
@@ -67,34 +68,8 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 // ---------------------------------------------------------------------------------------------
 // operator apply
 // ---------------------------------------------------------------------------------------------
-template <int DIM>
-__device__ __forceinline__ double stencil_eval(const double *__restrict__ w, const double *__restrict__ p, int len,
-                                               int A, int B)
-{
-    double acc = w[0] * p[0];
-    acc += w[1] * p[1];
-    acc += w[2] * p[-1];
-    acc += w[3] * p[len - 1];
-    acc += w[4] * p[-len];
-    acc += w[5] * p[len];
-    acc += w[6] * p[-len - 1];
-    if (DIM == 3) {
-        const double *pu = p + A;
-        const double *pd = p - B;
-        acc += w[7] * pu[-len];
-        acc += w[8] * pd[len + 1];
-        acc += w[9] * pu[-1];
-        acc += w[10] * pd[1];
-        acc += w[11] * pu[0];
-        acc += w[12] * pd[0];
-        acc += w[13] * pu[1 - len];
-        acc += w[14] * pd[len];
-    }
-    return acc;
-}
-
-// lambda < 0 is never a valid operator parameter; mass_only is signalled by the launcher through
-// a negative alpha_diff = 0 path instead: diff scale 0, mass scale alpha*lambda*|J|.
+// Per-cell scale of every operator term: alpha*|J|*P_kl for the diffusion terms, alpha*lambda*|J| for the
+// mass term; mass_only (next_rhs!) zeroes the diffusion part.
 template <int DIM>
 __device__ __forceinline__ void cell_scales(const double *__restrict__ cc, double alpha, double lambda, double *s,
                                             int mass_only = 0)

@@ -42,8 +42,8 @@ int hmg_ctx_create(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_create_on_stream(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_destroy(hmg_ctx *ctx);
 int hmg_ctx_sync(hmg_ctx *ctx);
-/* option names: "apply_variant" (0 generic, 1 persistent), "apply_threads", "coarse_maxit",
- * "coarse_check" ; "coarse_rtol" via hmg_ctx_set_option_f64 */
+/* option names: "apply_threads" (workgroup size of the apply kernel, 0 = auto), "fuse_cg" (1 = fused CG pass,
+ * default), "coarse_maxit", "coarse_check", "time_apply"; "coarse_rtol" via hmg_ctx_set_option_f64 */
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
 int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value);
 /* HIP-event timing of the operator-apply launches of levels >= the value given to option "time_apply"

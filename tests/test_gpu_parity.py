@@ -77,12 +77,12 @@ def test_device_rand_matches_host_twin(case3):
     np.testing.assert_array_equal(d.to_host(), hmg.host_random(d.shape, 1234, 5))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("threads", [0, 256, 512, 640])
 @pytest.mark.parametrize("which", ["case3", "case2"])
-def test_apply_matches_oracle(request, ctx, which, variant):
-    """mul!(alpha, base, A, x, y) -- ref: src/apply_local_operators.jl:85-133"""
+def test_apply_matches_oracle(request, ctx, which, threads):
+    """mul!(alpha, base, A, x, y) -- ref: src/apply_local_operators.jl:85-133 (every workgroup-size variant)"""
     c = request.getfixturevalue(which)
-    ctx.set_option("apply_variant", variant)
+    ctx.set_option("apply_threads", threads)
     try:
         for lev in range(1, c.levels + 1):
             x, y = c.rand(lev), c.rand(lev)
@@ -92,7 +92,7 @@ def test_apply_matches_oracle(request, ctx, which, variant):
             hmg.mul(-1.3, c.g, c.A, dx, dy)
             assert relerr(dy.to_host(), want) <= TOL, (which, lev)
     finally:
-        ctx.set_option("apply_variant", 1)
+        ctx.set_option("apply_threads", 0)
 
 
 @pytest.mark.parametrize("which", ["case3", "case2"])

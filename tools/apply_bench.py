@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the finest-level operator apply (used under rocprofv3 for the roofline numbers).
-  python tools/apply_bench.py [--width 32] [--levels 6] [--reps 10] [--variant V] [--threads T] [--mode ap|mul|res]
+  python tools/apply_bench.py [--width 32] [--levels 6] [--reps 10] [--threads T] [--mode ap|mul|res]
 """
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,14 +13,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=32)
 ap.add_argument("--levels", type=int, default=6)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--variant", type=int, default=None)
 ap.add_argument("--threads", type=int, default=None)
 ap.add_argument("--mode", default="ap")
 ap.add_argument("--others", action="store_true", help="also time interface sum / vector kernels / transfer")
 a = ap.parse_args()
 ctx = hmg.Context(0)
-if a.variant is not None:
-    ctx.set_option("apply_variant", a.variant)
 if a.threads is not None:
     ctx.set_option("apply_threads", a.threads)
 L = a.levels
