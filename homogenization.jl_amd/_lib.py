@@ -16,6 +16,7 @@ p_f64 = ctypes.POINTER(ctypes.c_double)
 pp = ctypes.POINTER(ctypes.c_void_p)
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+EXCHANGE_END_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 
 # name -> (restype, argtypes); every symbol declared in include/hmg.h
 SIGNATURES = {
@@ -75,6 +76,8 @@ SIGNATURES = {
     "hmg_grid_set_cut": (c_int, [vp, c_i64, c_i64, c_i64, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32]),
     "hmg_grid_set_exchange": (c_int, [vp, EXCHANGE_FN, EXCHANGE_FN, vp, vp, c_i64]),
     "hmg_grid_cut_buffer_doubles": (c_i64, [vp, c_int]),
+    "hmg_grid_set_exchange_async": (c_int, [vp, EXCHANGE_FN, EXCHANGE_END_FN]),
+    "hmg_grid_set_overlap": (c_int, [vp, c_int]),
     "hmg_ctx_set_scalar_bank": (c_int, [vp, vp]),
     "hmg_grid_create_partition": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, p_i32, c_int, c_int, pp]),
 }

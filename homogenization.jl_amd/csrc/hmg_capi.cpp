@@ -129,6 +129,10 @@ struct hmg_grid {
     DevBuf<int32_t> d_nodes_g, d_owned, d_cells_gnode;
     CutKind cut[3];   // faces, edges, nodes
     hmg_exchange_fn exchange = nullptr, scalar_sum = nullptr;
+    hmg_exchange_fn ex_begin = nullptr;          // asynchronous form: begin issues the sum, end waits for it
+    int (*ex_end)(void *) = nullptr;
+    bool overlap = true;
+    DevBuf<int32_t> d_cells_cut, d_cells_inner;
     void *ex_user = nullptr;
     double *ex_buf = nullptr;
     int64_t ex_cap = 0;
@@ -222,6 +226,14 @@ void upload_mesh(hmg_grid *g)
     d.dupmask = g->d_dupmask.p;
     d.mult = g->d_mult.p;
     d.blockpart = g->d_blockpart.p;
+    g->d_cells_cut.upload(M.cells_cut, s);
+    g->d_cells_inner.upload(M.cells_inner, s);
+    d.cells_cut = g->d_cells_cut.p;
+    d.cells_inner = g->d_cells_inner.p;
+    d.ncells_cut = (int64_t)M.cells_cut.size();
+    d.ncells_inner = (int64_t)M.cells_inner.size();
+    d.ncut_edge_groups = M.ncut_edge_groups;
+    d.ncut_node_groups = M.ncut_node_groups;
     d.coef = g->d_coef.p;
 }
 
@@ -390,7 +402,7 @@ void apply(hmg_grid *g, const LevelDev &lv, double alpha, const double *x, const
 void interface_sum(hmg_grid *g, const LevelDev &lv, double *x)
 {
     launch_interface_sum(g->ctx->L, lv, g->md, x);
-    if (g->exchange) exchange_cut(g, lv, x);
+    if (g->exchange || g->ex_begin) exchange_cut(g, lv, x);
 }
 
 void scalar_sum(hmg_grid *g, int slot, int count)
@@ -401,14 +413,17 @@ void scalar_sum(hmg_grid *g, int slot, int count)
     }
 }
 
-// one fused CG pass: p = r (+ beta*p), Ap = constraint(A p), partial sums for p.Ap (and r.r)
-void apply_fused(hmg_grid *g, const LevelDev &lv, const double *r, const double *pold, double *p, double *Ap,
-                 int s_num, int s_den, int slot_pap, int slot_rr)
-{
-    hmg_ctx *c = g->ctx;
-    ApplyTimer &t = c->timer;
-    const bool timed = t.on && lv.level >= t.min_level;
-    if (timed) {
+int64_t cut_doubles(const hmg_grid *g, const LevelDev &lv);
+void cut_pack(hmg_grid *g, const LevelDev &lv, double *x, int unpack);
+
+struct TimedRegion {   // HIP-event bracket of the finest-level operator applies (bench.py roofline)
+    hmg_ctx *c;
+    bool timed;
+    TimedRegion(hmg_grid *g, const LevelDev &lv, double bytes) : c(g->ctx)
+    {
+        ApplyTimer &t = c->timer;
+        timed = t.on && lv.level >= t.min_level;
+        if (!timed) return;
         if (t.used == t.pool.size()) {
             hipEvent_t a, b;
             HIPCHK(hipEventCreate(&a));
@@ -416,25 +431,69 @@ void apply_fused(hmg_grid *g, const LevelDev &lv, const double *r, const double 
             t.pool.emplace_back(a, b);
         }
         HIPCHK(hipEventRecord(t.pool[t.used].first, c->stream));
+        t.bytes += bytes;
     }
-    ApplyArgs a{};
-    a.alpha = 1.0;
-    a.lambda = g->lambda;
-    a.x = r;
-    a.x2 = pold;
-    a.xout = p;
-    a.src = nullptr;
-    a.out = Ap;
-    a.s_num = s_num;
-    a.s_den = s_den;
-    a.flags = 1;
-    launch_apply_fused(c->L, lv, g->md, a, slot_pap, slot_rr);
-    if (timed) {
+    void stop()
+    {
+        if (!timed) return;
+        ApplyTimer &t = c->timer;
         HIPCHK(hipEventRecord(t.pool[t.used].second, c->stream));
         t.used += 1;
         t.launches += 1;
-        t.bytes += 8.0 * (double)lv.nf * (double)g->md.ncells * (pold ? 4.0 : 3.0);
+        timed = false;
     }
+};
+
+// out = (src ? src : 0) + alpha*A*xin with the Dirichlet constraint, followed by the interface sum of
+// `out` (local + across ranks).  fused: the CG extras of k_apply<.., FUSED> (xin = x + beta*x2 written to
+// xout, scal[slot_pap] = sum mult*xin*out, scal[slot_rr] = sum xin*xin), summed over ranks.
+// On a partitioned grid the cells that own a copy of a cut entity go first; their cut DOFs are packed and
+// the sum over ranks is started, then the remaining cells and interface entities are processed while it
+// is in flight.
+void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, int slot_pap, int slot_rr)
+{
+    hmg_ctx *c = g->ctx;
+    const Launch &L = c->L;
+    set_slab(g, lv);
+    const double streams = 2.0 + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0);
+    TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
+    const int64_t ncut = g->exchange || g->ex_begin ? cut_doubles(g, lv) : 0;
+    const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 &&
+                         apply_lds_bytes(lv) <= 160 * 1024 && g->md.ncells_cut > 0;
+    auto launch = [&](const int32_t *list, int64_t n) {
+        ApplyArgs b = a;
+        b.cell_list = list;
+        b.ncell_list = n;
+        if (fused)
+            launch_apply_fused_kernel(L, lv, g->md, b);
+        else
+            launch_apply_args(L, lv, g->md, b);
+    };
+    auto sums = [&]() {
+        if (!fused) return;
+        launch_apply_fused_reduce(L, g->md, slot_pap, slot_rr);
+        if (slot_rr >= 0) scalar_sum(g, slot_rr, 1);
+        scalar_sum(g, slot_pap, 1);
+    };
+    if (!overlap) {
+        launch(nullptr, 0);
+        tr.stop();
+        sums();
+        interface_sum(g, lv, a.out);
+        return;
+    }
+    need(ncut <= g->ex_cap, "exchange buffer too small for this level");
+    launch(g->md.cells_cut, g->md.ncells_cut);
+    launch_interface_sum(L, lv, g->md, a.out, 1);        // local copies of the cut entities
+    launch_fill(L, g->ex_buf, ncut, 0.0);
+    cut_pack(g, lv, a.out, 0);
+    if (g->ex_begin(g->ex_user, g->ex_buf, ncut) != 0) throw std::runtime_error("exchange (begin) callback failed");
+    launch(g->md.cells_inner, g->md.ncells_inner);        // overlaps the sum over ranks
+    tr.stop();
+    launch_interface_sum(L, lv, g->md, a.out, 2);
+    sums();
+    if (g->ex_end(g->ex_user) != 0) throw std::runtime_error("exchange (end) callback failed");
+    cut_pack(g, lv, a.out, 1);
 }
 
 // keep_p = false skips the reference's last p-update (src/multigrid.jl:68) when its result is dead: inside a
@@ -446,27 +505,38 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
     const LevelDev &lv = lev(g, level);
     const Launch &L = g->ctx->L;
     const int64_t n = vec_len(x);
-    apply(g, lv, -1.0, x->d, b->d, r->d, 1);                            // r = b - A x, constraint
-    interface_sum(g, lv, r->d);
+    {
+        ApplyArgs a{};                                                    // r = b - A x, constraint, interface sum
+        a.alpha = -1.0;
+        a.lambda = g->lambda;
+        a.x = x->d;
+        a.src = b->d;
+        a.out = r->d;
+        a.flags = 1;
+        apply_then_sum(g, lv, a, false, -1, -1);
+    }
     int cur = S_RS, other = S_RS2;
     if (g->fuse_cg && apply_lds_bytes(lv) <= 160 * 1024) {
         // p-update and both reductions ride along with the operator apply (see k_apply<.., FUSED>)
         for (int i = 0; i < steps; ++i) {
-            if (i == 0) {
-                apply_fused(g, lv, r->d, nullptr, p->d, Ap->d, 0, 0, S_PAP, cur);   // p = r; rs = r.r
-                scalar_sum(g, cur, 1);
-            } else
-                apply_fused(g, lv, r->d, p->d, p->d, Ap->d, cur, other, S_PAP, -1); // beta = rs'/rs
-            scalar_sum(g, S_PAP, 1);
-            interface_sum(g, lv, Ap->d);
-            launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);
+            ApplyArgs a{};
+            a.alpha = 1.0;
+            a.lambda = g->lambda;
+            a.x = r->d;
+            a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
+            a.xout = p->d;
+            a.out = Ap->d;
+            a.s_num = cur;
+            a.s_den = other;
+            a.flags = 1;
+            apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1);
+            launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs / p.Ap
             scalar_sum(g, other, 1);
             std::swap(cur, other);
         }
         if (steps > 0) {
             if (keep_p) launch_cg_pupdate(L, p->d, r->d, n, cur, other);   // the reference's last p-update
-        }
-        else {
+        } else {
             launch_copy_dot(L, p->d, r->d, n, cur);
             scalar_sum(g, cur, 1);
         }
@@ -608,6 +678,20 @@ int64_t cut_doubles(const hmg_grid *g, const LevelDev &lv)
     return g->cut[0].nglobal * lv.nfi + g->cut[1].nglobal * lv.nei + g->cut[2].nglobal;
 }
 
+// unpack = 0: buffer[cut id] <- first local copy;  unpack = 1: every local copy <- buffer[cut id]
+void cut_pack(hmg_grid *g, const LevelDev &lv, double *x, int unpack)
+{
+    const Launch &L = g->ctx->L;
+    int64_t off = 0;
+    const int per[3] = {lv.nfi, lv.nei, 1};
+    for (int k = 0; k < 3; ++k) {
+        if (g->cut[k].nentries && per[k])
+            launch_cut_pack(L, lv, k, g->cut[k].nentries, g->cut[k].gid.p, g->cut[k].cell_lid.p, g->cut[k].first.p,
+                            g->ex_buf + off, x, unpack);
+        off += g->cut[k].nglobal * per[k];
+    }
+}
+
 void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x)
 {
     const Launch &L = g->ctx->L;
@@ -615,22 +699,14 @@ void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x)
     if (n == 0) return;
     need(n <= g->ex_cap, "exchange buffer too small for this level");
     launch_fill(L, g->ex_buf, n, 0.0);
-    int64_t off = 0;
-    const int per[3] = {lv.nfi, lv.nei, 1};
-    for (int k = 0; k < 3; ++k) {
-        if (g->cut[k].nentries && per[k])
-            launch_cut_pack(L, lv, k, g->cut[k].nentries, g->cut[k].gid.p, g->cut[k].cell_lid.p, g->cut[k].first.p,
-                            g->ex_buf + off, x, 0);
-        off += g->cut[k].nglobal * per[k];
+    cut_pack(g, lv, x, 0);
+    if (g->exchange) {
+        if (g->exchange(g->ex_user, g->ex_buf, n) != 0) throw std::runtime_error("exchange callback failed");
+    } else {
+        if (g->ex_begin(g->ex_user, g->ex_buf, n) != 0 || g->ex_end(g->ex_user) != 0)
+            throw std::runtime_error("exchange callback failed");
     }
-    if (g->exchange(g->ex_user, g->ex_buf, n) != 0) throw std::runtime_error("exchange callback failed");
-    off = 0;
-    for (int k = 0; k < 3; ++k) {
-        if (g->cut[k].nentries && per[k])
-            launch_cut_pack(L, lv, k, g->cut[k].nentries, g->cut[k].gid.p, g->cut[k].cell_lid.p, g->cut[k].first.p,
-                            g->ex_buf + off, x, 1);
-        off += g->cut[k].nglobal * per[k];
-    }
+    cut_pack(g, lv, x, 1);
 }
 
 }  // namespace
@@ -1451,6 +1527,23 @@ int hmg_grid_set_exchange(hmg_grid *g, hmg_exchange_fn exchange, hmg_exchange_fn
     g->ex_user = user;
     g->ex_buf = (double *)device_exchange_buf;
     g->ex_cap = exchange_buf_doubles;
+    HMG_END
+}
+
+int hmg_grid_set_exchange_async(hmg_grid *g, hmg_exchange_fn begin, int (*end)(void *user))
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    g->ex_begin = begin;
+    g->ex_end = end;
+    HMG_END
+}
+
+int hmg_grid_set_overlap(hmg_grid *g, int enabled)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    g->overlap = enabled != 0;
     HMG_END
 }
 

@@ -43,6 +43,9 @@ struct MeshDev {
     const int32_t *node_first;   // nnodes
     const uint16_t *dmask, *dupmask;
     const double *coef;          // 8 per cell
+    int64_t ncut_edge_groups, ncut_node_groups;   // leading groups of the edge / node CSR that are cut
+    const int32_t *cells_cut, *cells_inner;       // partitioned grids: cell lists for the overlapped exchange
+    int64_t ncells_cut, ncells_inner;
     const uint8_t *mult;         // 16 per cell: number of copies of each entity (bit order of the masks)
     double *blockpart;           // 2 per cell: scratch for the fused apply's block sums
     // slab decomposition of the finest level when one cell exceeds the LDS (set per launch by the host)
@@ -62,6 +65,8 @@ struct ApplyArgs {
     double *blockpart;
     const uint8_t *mult;
     int flags;             // bit 0: Dirichlet constraint on out; bit 1: mass term only
+    const int32_t *cell_list;   // optional: workgroup b works on cell cell_list[b] (ncell_list of them)
+    int64_t ncell_list;
 };
 
 struct CoarseDev {
@@ -91,8 +96,13 @@ size_t apply_lds_bytes(const LevelDev &lv);
 // (slot_rr < 0: not wanted).  a.scal / a.mult / a.blockpart are filled in by the launcher.
 void launch_apply_fused(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a, int slot_pap,
                         int slot_rr);
+// the two halves of launch_apply_fused, for callers that split the cells over several launches
+void launch_apply_fused_kernel(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);
+void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pap, int slot_rr);
+void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);
 
-void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x);
+// which: 0 everything; 1 only the cut edge / node groups; 2 everything else (faces, non-cut groups)
+void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which = 0);
 void launch_mask(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which /*0 dmask,1 dupmask*/);
 void launch_restrict(const Launch &L, const LevelDev &fine, const LevelDev &coarse, int64_t ncells,
                      const double *rf, double *bc);

@@ -95,6 +95,12 @@ struct MeshTables {
     // boundary (Dirichlet) base nodes flag
     std::vector<uint8_t> node_on_boundary;
 
+    // partitioned grids only: shared edge / node groups whose entity is cut by the partition are listed
+    // first (ncut_*_groups of them); cells_cut = local cells that own a copy of any cut entity,
+    // cells_inner = the others.  Used to overlap the exchange with the work that does not feed it.
+    int64_t ncut_edge_groups = 0, ncut_node_groups = 0;
+    std::vector<int32_t> cells_cut, cells_inner;
+
     // cell geometry: detJ and Jinv = inv(J') (column-major dim x dim)
     std::vector<double> detj, jinv;
 };

@@ -203,7 +203,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     double *W = smem;
     double *xs = smem + WSZ + lv.lds_g0;
     const int tid = threadIdx.x;
-    const int64_t cell = blockIdx.x;
+    const int64_t cell = a.cell_list ? (int64_t)a.cell_list[blockIdx.x] : (int64_t)blockIdx.x;
     const int nf = lv.nf;
 
     double s[NTERM];
@@ -433,7 +433,9 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
     auto kern = k_apply<DIM, NT, SPT, FUSED>;
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, a);
+    const int64_t nblocks = a.cell_list ? a.ncell_list : mesh.ncells;
+    if (nblocks == 0) return;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, a);
     check_launch();
 }
 
@@ -447,6 +449,7 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         auto kern = k_apply_slab<DIM, 1024>;
         const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab_lds_nodes);
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        if (a.cell_list) throw std::runtime_error("cell lists are not supported by the slab apply");
         hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
                            mesh.slab_k, mesh.nslab, mesh.slab_lds_nodes);
         check_launch();
@@ -483,6 +486,36 @@ void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, doub
         launch_apply_dim<3, false>(L, lv, mesh, a);
     else
         launch_apply_dim<2, false>(L, lv, mesh, a);
+}
+
+void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a)
+{
+    a.flags = (a.flags & 1) | (L.apply_mass_only ? 2 : 0);
+    if (lv.dim == 3)
+        launch_apply_dim<3, false>(L, lv, mesh, a);
+    else
+        launch_apply_dim<2, false>(L, lv, mesh, a);
+}
+
+void launch_apply_fused_kernel(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a)
+{
+    a.scal = L.scal;
+    a.mult = mesh.mult;
+    a.blockpart = mesh.blockpart;
+    if (lv.dim == 3)
+        launch_apply_dim<3, true>(L, lv, mesh, a);
+    else
+        launch_apply_dim<2, true>(L, lv, mesh, a);
+}
+
+void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pap, int slot_rr)
+{
+    hipLaunchKernelGGL(k_reduce_pairs, dim3(256), dim3(256), 0, L.stream, mesh.blockpart, mesh.ncells, L.partials);
+    check_launch();
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, 256, L.scal, slot_pap);
+    if (slot_rr >= 0)
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, 256, L.scal, slot_rr);
+    check_launch();
 }
 
 void launch_apply_fused(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a, int slot_pap, int slot_rr)
@@ -545,30 +578,36 @@ k_iface_csr(const int32_t *__restrict__ ptr, const int32_t *__restrict__ ent, in
     }
 }
 
-void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x)
+void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which)
 {
     const int cap = L.num_cu * 8;
-    if (lv.dim == 3 && lv.nfi > 0 && mesh.nfacepairs > 0) {
+    if (which != 1 && lv.dim == 3 && lv.nfi > 0 && mesh.nfacepairs > 0) {
         int64_t blocks = (mesh.nfacepairs + 3) / 4;
-        if (lv.nfi < 64) blocks = (mesh.nfacepairs + 3) / 4;
         if (blocks > cap * 4) blocks = cap * 4;
         hipLaunchKernelGGL(k_iface_faces, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.face_pairs,
                            mesh.nfacepairs, lv.nfi, lv.off_face, lv.ld, x);
         check_launch();
     }
-    if (lv.nei > 0 && mesh.nsharededges > 0) {
-        int64_t total = mesh.nsharededges * lv.nei;
-        int64_t blocks = (total + 255) / 256;
+    // group ranges of the CSR lists: [0, ncut) are cut by the partition, [ncut, n) are not
+    auto range = [&](int64_t n, int64_t ncut, int64_t &first, int64_t &count) {
+        first = which == 2 ? ncut : 0;
+        count = which == 1 ? ncut : which == 2 ? n - ncut : n;
+    };
+    int64_t first, count;
+    range(mesh.nsharededges, mesh.ncut_edge_groups, first, count);
+    if (lv.nei > 0 && count > 0) {
+        int64_t blocks = (count * lv.nei + 255) / 256;
         if (blocks > cap * 4) blocks = cap * 4;
-        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.edge_ptr, mesh.edge_ent,
-                           mesh.nsharededges, lv.nei, lv.off_edge, lv.ld, x);
+        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.edge_ptr + first,
+                           mesh.edge_ent, count, lv.nei, lv.off_edge, lv.ld, x);
         check_launch();
     }
-    if (mesh.nsharednodes > 0) {
-        int64_t blocks = (mesh.nsharednodes + 255) / 256;
+    range(mesh.nsharednodes, mesh.ncut_node_groups, first, count);
+    if (count > 0) {
+        int64_t blocks = (count + 255) / 256;
         if (blocks > cap * 4) blocks = cap * 4;
-        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.node_ptr, mesh.node_ent,
-                           mesh.nsharednodes, 1, 0, lv.ld, x);
+        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.node_ptr + first,
+                           mesh.node_ent, count, 1, 0, lv.ld, x);
         check_launch();
     }
 }

@@ -307,6 +307,24 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
         local.node_on_boundary[q] = G.node_on_boundary[part.nodes_g[q]];
     }
 
+    auto cut_first = [&](std::vector<int32_t> &ptr, std::vector<int32_t> &ent, const std::vector<int32_t> &cut_entries) {
+        // stable partition of the CSR groups: groups containing a cut entry first
+        std::unordered_set<int32_t> cs(cut_entries.begin(), cut_entries.end());
+        std::vector<int32_t> nptr{0}, nent;
+        int64_t ncut = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t gidx = 0; gidx + 1 < ptr.size(); ++gidx) {
+                bool is_cut = cs.count(ent[ptr[gidx]]) != 0;
+                if (is_cut != (pass == 0)) continue;
+                for (int32_t q = ptr[gidx]; q < ptr[gidx + 1]; ++q) nent.push_back(ent[q]);
+                nptr.push_back((int32_t)nent.size());
+                if (pass == 0) ++ncut;
+            }
+        ptr.swap(nptr);
+        ent.swap(nent);
+        return ncut;
+    };
+
     // entities whose copies live on more than one rank get a global cut id (same on every rank)
     for (int kind = 0; kind < 3; ++kind) {
         part.nglobal[kind] = 0;
@@ -329,6 +347,15 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
                 }
         });
     }
+    local.ncut_edge_groups = cut_first(local.edge_ptr, local.edge_ent, part.cell_lid[1]);
+    local.ncut_node_groups = cut_first(local.node_ptr, local.node_ent, part.cell_lid[2]);
+    std::vector<uint8_t> is_cut_cell(part.cells_g.size(), 0);
+    for (int kind = 0; kind < 3; ++kind)
+        for (int32_t v : part.cell_lid[kind]) is_cut_cell[v >> 3] = 1;
+    local.cells_cut.clear();
+    local.cells_inner.clear();
+    for (size_t q = 0; q < is_cut_cell.size(); ++q)
+        (is_cut_cell[q] ? local.cells_cut : local.cells_inner).push_back((int32_t)q);
 }
 
 void build_cell_coefficients(const MeshTables &M, const double *sigma, std::vector<double> &coef)

@@ -89,10 +89,37 @@ class Exchange:
                 print("hmg scalar sum failed:", e, flush=True)
                 return 1
 
-        self._cb = (L.EXCHANGE_FN(_exchange), L.EXCHANGE_FN(_scalar))      # keep alive
+        self._work = None
+
+        def _begin(user, ptr, count):
+            try:
+                off = (ptr - self.buf.data_ptr()) // 8
+                self._work = self.dist.all_reduce(self.buf[off:off + count], group=self.group, async_op=True)
+                self.calls += 1
+                return 0
+            except Exception as e:
+                print("hmg exchange (begin) failed:", e, flush=True)
+                return 1
+
+        def _end(user):
+            try:
+                if self._work is not None:
+                    self._work.wait()          # NCCL: the current stream waits; gloo: the host waits
+                    self._work = None
+                return 0
+            except Exception as e:
+                print("hmg exchange (end) failed:", e, flush=True)
+                return 1
+
+        self._cb = (L.EXCHANGE_FN(_exchange), L.EXCHANGE_FN(_scalar), L.EXCHANGE_FN(_begin),
+                    L.EXCHANGE_END_FN(_end))                                # keep alive
         L.check(lib.hmg_grid_set_exchange(grid.h, self._cb[0], self._cb[1], None,
                                           ctypes.c_void_p(self.buf.data_ptr()), n))
+        L.check(lib.hmg_grid_set_exchange_async(grid.h, self._cb[2], self._cb[3]))
         grid._exchange = self
+
+    def set_overlap(self, grid, enabled: bool):
+        L.check(L.load().hmg_grid_set_overlap(grid.h, 1 if enabled else 0))
 
 
 def block_shape(world: int, dim: int = 3):

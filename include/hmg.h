@@ -149,6 +149,11 @@ int hmg_grid_set_cut(hmg_grid *grid, int64_t ncut_global_faces, int64_t ncut_glo
                      int64_t nlocal_nodes, const int64_t *node_gid, const int32_t *node_cell_lid);
 int hmg_grid_set_exchange(hmg_grid *grid, hmg_exchange_fn exchange, hmg_exchange_fn scalar_sum, void *user,
                           void *device_exchange_buf, int64_t exchange_buf_doubles);
+/* Asynchronous form of the exchange: begin() starts the in-place sum over ranks of device_buf[0..count) and
+ * returns, end() makes the context's stream wait for it.  With it the smoother overlaps the exchange with the
+ * apply / interface sums of the cells that do not touch a partition cut (hmg_grid_set_overlap, default on). */
+int hmg_grid_set_exchange_async(hmg_grid *grid, hmg_exchange_fn begin, int (*end)(void *user));
+int hmg_grid_set_overlap(hmg_grid *grid, int enabled);
 /* level = 0: capacity needed for every level and for the coarse gather */
 int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *grid, int level);
 void *hmg_ctx_scalar_bank(hmg_ctx *ctx);

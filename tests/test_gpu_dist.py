@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, levels, q):
+def _worker(rank, world, port, width, levels, overlap, q):
     try:
         sys.path.insert(0, ROOT)
         import torch
@@ -37,6 +37,7 @@ def _worker(rank, world, port, width, levels, q):
         ctx = hmg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
         prob = hdist.partitioned_checkerboard(ctx, width, levels, world, rank, seed=3)
         g = prob.implicit
+        prob.exchange.set_overlap(g, overlap)
         L = levels
         # serial oracle on the global mesh with the same inputs
         gm = O.Mesh(prob.global_base.nodes, prob.global_base.elements - 1)
@@ -74,12 +75,14 @@ def _worker(rank, world, port, width, levels, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-def test_two_rank_vcycle_matches_serial_oracle():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_rank_vcycle_matches_serial_oracle(overlap):
+    """overlap=True: cut-adjacent cells first, asynchronous sum over ranks in flight during the rest."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 2, 4, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 4, 4, overlap, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
