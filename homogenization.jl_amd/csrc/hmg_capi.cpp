@@ -518,6 +518,11 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
     int cur = S_RS, other = S_RS2;
     if (g->fuse_cg && apply_lds_bytes(lv) <= 160 * 1024) {
         // p-update and both reductions ride along with the operator apply (see k_apply<.., FUSED>)
+        // Per step:  fused apply  [x += alpha_prev p_old;  p = r + beta p_old;  Ap = A p;  p.Ap (, r.r)]
+        //            interface sum of Ap
+        //            r -= alpha Ap;  r.r'
+        // The x-update of step i rides with the fused apply of step i+1 (which reads p anyway); the last one
+        // is done together with the reference's final p-update.
         for (int i = 0; i < steps; ++i) {
             ApplyArgs a{};
             a.alpha = 1.0;
@@ -525,17 +530,24 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
             a.x = r->d;
             a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
             a.xout = p->d;
+            a.xacc = i == 0 ? nullptr : x->d;                             // x += alpha_{i-1} p_{i-1}
+            a.a_num = other;                                              // rs_{i-1} (after the swap below)
+            a.a_den = S_PAP;                                              // p_{i-1}.Ap_{i-1}: still the old value here
             a.out = Ap->d;
             a.s_num = cur;
             a.s_den = other;
             a.flags = 1;
+            // (the kernels above read the previous p.Ap from S_PAP; the reduction that overwrites it is enqueued
+            //  behind them on the same stream)
             apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1);
-            launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs / p.Ap
+            launch_cg_rupdate(L, r->d, Ap->d, n, cur, S_PAP, other);      // alpha = rs / p.Ap
             scalar_sum(g, other, 1);
             std::swap(cur, other);
         }
         if (steps > 0) {
-            if (keep_p) launch_cg_pupdate(L, p->d, r->d, n, cur, other);   // the reference's last p-update
+            // x += alpha_last p (alpha_last = rs_{s-1} / p.Ap: `other` holds rs_{s-1} after the swap) and, if its
+            // result can be observed, the reference's last p-update p = r + (rs_s / rs_{s-1}) p
+            launch_cg_xp_update(L, x->d, p->d, r->d, n, other, S_PAP, cur, other, keep_p ? 1 : 0);
         } else {
             launch_copy_dot(L, p->d, r->d, n, cur);
             scalar_sum(g, cur, 1);

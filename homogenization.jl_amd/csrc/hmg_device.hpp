@@ -58,6 +58,8 @@ struct ApplyArgs {
     const double *x;       // input column; with x2: xin = x + beta * x2, beta = scal[s_num] / scal[s_den]
     const double *x2;
     double *xout;          // optional: xin written back (p-update / p = r)
+    double *xacc;          // optional: xacc += (scal[a_num] / scal[a_den]) * x2  (the previous step's x-update)
+    int a_num, a_den;
     const double *src;     // optional: out = src + alpha * A * xin
     double *out;
     const double *scal;
@@ -122,7 +124,12 @@ void launch_copy_dot(const Launch &L, double *p, const double *r, int64_t n, int
 // alpha = scal[s_num]/scal[s_den]; x += alpha p; r -= alpha q; scal[s_out] = r.r
 void launch_cg_update(const Launch &L, double *x, double *r, const double *p, const double *q, int64_t n,
                       int s_num, int s_den, int s_out);
-// beta = scal[s_num]/scal[s_den]; p = r + beta p; afterwards scal[s_den] = scal[s_num]
+// alpha = scal[s_num]/scal[s_den]; r -= alpha q; scal[s_out] = r.r
+void launch_cg_rupdate(const Launch &L, double *r, const double *q, int64_t n, int s_num, int s_den, int s_out);
+// x += (scal[a_num]/scal[a_den]) p; with_p: p = r + (scal[s_num]/scal[s_den]) p
+void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
+                         int s_num, int s_den, int with_p);
+// beta = scal[s_num]/scal[s_den]; p = r + beta p
 void launch_cg_pupdate(const Launch &L, double *p, const double *r, int64_t n, int s_num, int s_den);
 
 void launch_gather_base(const Launch &L, const MeshDev &mesh, int ld1, const double *v1, double *u);

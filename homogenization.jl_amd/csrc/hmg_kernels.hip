@@ -220,39 +220,50 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const double *xc = a.x + cell * lv.ld;
     double rr = 0.0, pap = 0.0;
     {
-        // Load phase in two passes -- all loads first, then stores / LDS writes -- so that the store to
-        // xout (which may be the same array as x2) never sits between two loads of the same wave.
+        // Load phase, in batches of HB slots per thread: all loads of a batch first, then its stores / LDS
+        // writes, so that a store to xout / xacc (which may alias x2) never sits between two loads of a batch.
+        // FUSED extras: xacc += ax * x2 (the previous CG step's x-update, x2 = p_old), xin = x + beta * x2.
         const double *x2c = FUSED && a.x2 ? a.x2 + cell * lv.ld : nullptr;
         double *xoc = FUSED && a.xout ? a.xout + cell * lv.ld : nullptr;
+        double *xac = FUSED && a.xacc ? a.xacc + cell * lv.ld : nullptr;
         const double beta = x2c ? a.scal[a.s_num] / a.scal[a.s_den] : 0.0;
-        double xv[SPT], x2v[SPT];
-        int lp[SPT];
+        const double ax = xac ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0;
+        constexpr int HB = FUSED ? (SPT + 1) / 2 : SPT;
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) {
-            const int t = tid + q * NT;
-            if (t < nf) {
-                xv[q] = xc[t];
-                x2v[q] = x2c ? x2c[t] : 0.0;
-                lp[q] = lv.lpos[t];
-            }
-        }
+        for (int q0 = 0; q0 < SPT; q0 += HB) {
+            double xv[HB], x2v[HB], xav[HB];
+            int lp[HB];
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) {
-            const int t = tid + q * NT;
-            if (t < nf) {
-                double v = xv[q];
-                if (FUSED) {
-                    if (x2c) v = v + beta * x2v[q];
-                    if (xoc) xoc[t] = v;
-                    rr += v * v;
+            for (int q = 0; q < HB; ++q) {
+                const int t = tid + (q0 + q) * NT;
+                if (q0 + q < SPT && t < nf) {
+                    xv[q] = xc[t];
+                    x2v[q] = x2c ? x2c[t] : 0.0;
+                    xav[q] = xac ? xac[t] : 0.0;
+                    lp[q] = lv.lpos[t];
                 }
-                xs[lp[q]] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int t = tid + (q0 + q) * NT;
+                if (q0 + q < SPT && t < nf) {
+                    double v = xv[q];
+                    if (FUSED) {
+                        if (xac) xac[t] = xav[q] + ax * x2v[q];
+                        if (x2c) v = v + beta * x2v[q];
+                        if (xoc) xoc[t] = v;
+                        rr += v * v;
+                    }
+                    xs[lp[q]] = v;
+                }
             }
         }
         for (int t = tid + SPT * NT; t < nf; t += NT) {   // only for cells larger than SPT*NT
             double v = xc[t];
             if (FUSED) {
-                if (x2c) v = v + beta * x2c[t];
+                const double pv = x2c ? x2c[t] : 0.0;
+                if (xac) xac[t] = xac[t] + ax * pv;
+                if (x2c) v = v + beta * pv;
                 if (xoc) xoc[t] = v;
                 rr += v * v;
             }
@@ -896,6 +907,65 @@ k_cg_update(double *x, double *r, const double *__restrict__ p, const double *__
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// r -= alpha q, partial r.r   (alpha = scal[s_num] / scal[s_den]); the x-update rides with the next fused apply
+__global__ void __launch_bounds__(256)
+k_cg_rupdate(double *r, const double *__restrict__ q, int64_t n, const double *__restrict__ scal, int s_num, int s_den,
+             double *partials)
+{
+    __shared__ double red[4];
+    const double alpha = scal[s_num] / scal[s_den];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *q2 = reinterpret_cast<const double2 *>(q);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 rv = r2[i], qv = q2[i];
+        rv.x += (-alpha) * qv.x;
+        rv.y += (-alpha) * qv.y;
+        r2[i] = rv;
+        acc += rv.x * rv.x;
+        acc += rv.y * rv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double rv = r[n - 1] + (-alpha) * q[n - 1];
+        r[n - 1] = rv;
+        acc += rv * rv;
+    }
+    double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// x += alpha p (alpha = scal[a_num]/scal[a_den]) and, if with_p, p = r + beta p (beta = scal[s_num]/scal[s_den])
+__global__ void __launch_bounds__(256)
+k_cg_xp_update(double *x, double *p, const double *__restrict__ r, int64_t n, const double *__restrict__ scal,
+               int a_num, int a_den, int s_num, int s_den, int with_p)
+{
+    const double alpha = scal[a_num] / scal[a_den];
+    const double beta = with_p ? scal[s_num] / scal[s_den] : 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n2 = n >> 1;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 xv = x2[i], pv = p2[i];
+        xv.x += alpha * pv.x;
+        xv.y += alpha * pv.y;
+        x2[i] = xv;
+        if (with_p) {
+            double2 rv = r2[i];
+            pv.x = rv.x + beta * pv.x;
+            pv.y = rv.y + beta * pv.y;
+            p2[i] = pv;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] += alpha * p[n - 1];
+        if (with_p) p[n - 1] = r[n - 1] + beta * p[n - 1];
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_cg_pupdate(double *p, const double *__restrict__ r, int64_t n, const double *__restrict__ scal, int s_num, int s_den)
 {
@@ -961,6 +1031,22 @@ void launch_cg_update(const Launch &L, double *x, double *r, const double *p, co
     check_launch();
     finalize(L, nb, s_out);
 }
+void launch_cg_rupdate(const Launch &L, double *r, const double *q, int64_t n, int s_num, int s_den, int s_out)
+{
+    int nb = stream_blocks(L, n, 8);
+    hipLaunchKernelGGL(k_cg_rupdate, dim3(nb), dim3(256), 0, L.stream, r, q, n, L.scal, s_num, s_den, L.partials);
+    check_launch();
+    finalize(L, nb, s_out);
+}
+
+void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
+                         int s_num, int s_den, int with_p)
+{
+    hipLaunchKernelGGL(k_cg_xp_update, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, x, p, r, n, L.scal, a_num,
+                       a_den, s_num, s_den, with_p);
+    check_launch();
+}
+
 void launch_cg_pupdate(const Launch &L, double *p, const double *r, int64_t n, int s_num, int s_den)
 {
     hipLaunchKernelGGL(k_cg_pupdate, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, p, r, n, L.scal, s_num,
