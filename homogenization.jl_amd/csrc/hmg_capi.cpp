@@ -455,7 +455,8 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     hmg_ctx *c = g->ctx;
     const Launch &L = c->L;
     set_slab(g, lv);
-    const double streams = 2.0 + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0);
+    // algorithmic HBM streams of this launch: x in, out, + src, + x2 (p_old), + xout (p), + xacc (x read and write)
+    const double streams = 2.0 + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) + (a.xacc ? 2.0 : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
     const int64_t ncut = g->exchange || g->ex_begin ? cut_doubles(g, lv) : 0;
     const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 &&

@@ -114,29 +114,31 @@ __device__ __forceinline__ double stencil_eval_v(const double *w, const double *
     return acc;
 }
 
-// surface nodes: zero-weight taps may address below the lattice image (plane -1 / row -1): clamp to 0
+// Surface nodes: the weight row comes from the LDS class table, read tap by tap (volatile LDS reads keep
+// this order, so only a few registers are live); zero-weight taps may address below the lattice image
+// (plane -1 / row -1) and are clamped to 0.
 template <int DIM>
-__device__ __forceinline__ double stencil_eval_c(const double *w, const double *base, int L, int len, int A, int B,
+__device__ __forceinline__ double stencil_eval_c(const double *wr, const double *base, int L, int len, int A, int B,
                                                  double &ctr)
 {
     auto at = [&](int off) { return lds_ld(base + max(L + off, 0)); };
     ctr = lds_ld(base + L);
-    double acc = w[0] * ctr;
-    acc += w[1] * lds_ld(base + L + 1);
-    acc += w[2] * at(-1);
-    acc += w[3] * lds_ld(base + L + len - 1);
-    acc += w[4] * at(-len);
-    acc += w[5] * lds_ld(base + L + len);
-    acc += w[6] * at(-len - 1);
+    double acc = lds_ld(wr + 0) * ctr;
+    acc += lds_ld(wr + 1) * lds_ld(base + L + 1);
+    acc += lds_ld(wr + 2) * at(-1);
+    acc += lds_ld(wr + 3) * lds_ld(base + L + len - 1);
+    acc += lds_ld(wr + 4) * at(-len);
+    acc += lds_ld(wr + 5) * lds_ld(base + L + len);
+    acc += lds_ld(wr + 6) * at(-len - 1);
     if (DIM == 3) {
-        acc += w[7] * lds_ld(base + L + A - len);
-        acc += w[8] * at(len + 1 - B);
-        acc += w[9] * lds_ld(base + L + A - 1);
-        acc += w[10] * at(1 - B);
-        acc += w[11] * lds_ld(base + L + A);
-        acc += w[12] * at(-B);
-        acc += w[13] * lds_ld(base + L + A + 1 - len);
-        acc += w[14] * at(len - B);
+        acc += lds_ld(wr + 7) * lds_ld(base + L + A - len);
+        acc += lds_ld(wr + 8) * at(len + 1 - B);
+        acc += lds_ld(wr + 9) * lds_ld(base + L + A - 1);
+        acc += lds_ld(wr + 10) * at(1 - B);
+        acc += lds_ld(wr + 11) * lds_ld(base + L + A);
+        acc += lds_ld(wr + 12) * at(-B);
+        acc += lds_ld(wr + 13) * lds_ld(base + L + A + 1 - len);
+        acc += lds_ld(wr + 14) * at(len - B);
     }
     return acc;
 }
@@ -271,6 +273,9 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
     }
 
+    // (scheduling fence: keeps the table prefetch below out of the load phase's register budget -- the
+    //  1024-thread variants must stay within 64 VGPRs to keep two workgroups resident per CU)
+    __builtin_amdgcn_sched_barrier(0);
     // compact addressing words, fetched two iterations ahead of their use so that the L2 latency of
     // the table never sits in a thread's dependent chain
     const int m = lv.m;
@@ -285,11 +290,11 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     uint32_t q1 = tid + NT < nsw ? lv.sweep32[tid + NT] : 0u;
     int s0 = tid < nsw ? (int)lv.sweep_slot[tid] : 0xffff;
     int s1 = tid + NT < nsw ? (int)lv.sweep_slot[tid + NT] : 0xffff;
-    uint64_t mq0 = 0, mq1 = 0;
+    uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
     if (FUSED) {
-        const uint64_t *mp = reinterpret_cast<const uint64_t *>(a.mult + cell * 16);
-        mq0 = mp[0];
-        mq1 = mp[1];
+        const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mq[q] = __builtin_amdgcn_readfirstlane(mp[q]);
     }
     __syncthreads();
 
@@ -301,17 +306,14 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         const double sv = sc ? sc[t] : 0.0;
         int L, len, A, B, cls;
         decode32<DIM>(pw, m, L, len, A, B, cls);
-        const double *wr = W + cls * NDIR;
-        double w[NDIR];
-#pragma unroll
-        for (int d = 0; d < NDIR; ++d) w[d] = lds_ld(wr + d);
         double ctr;
-        double o = sv + stencil_eval_c<DIM>(w, xs, L, len, A, B, ctr);
+        double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
         if ((dm >> (cls - 1)) & 1u) o = 0.0;
         oc[t] = o;
         if (FUSED) {
             const int e = cls - 1;
-            const uint32_t mu = (uint32_t)((e < 8 ? mq0 >> (8 * e) : mq1 >> (8 * (e - 8))) & 0xffu);
+            const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
+            const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
             pap += (double)mu * (ctr * o);
         }
     }
@@ -1390,12 +1392,8 @@ k_integrate(LevelDev lv, const double *__restrict__ coef, int mode, const double
     for (int t = tid; t < nf; t += NT) {
         int L, len, A, B, cls;
         decode32<DIM>(lv.pos32[t], lv.m, L, len, A, B, cls);
-        const double *wr = W + cls * NDIR;
-        double w[NDIR];
-#pragma unroll
-        for (int d = 0; d < NDIR; ++d) w[d] = lds_ld(wr + d);
         double ctr;
-        const double mv = stencil_eval_c<DIM>(w, xs, L, len, A, B, ctr);
+        const double mv = stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
         if (mode == 0) {
             const double *d = lv.dphi + 3 * t;
             double dp = d[0] * p0;

@@ -9,7 +9,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = sorted(glob.glob(os.path.join(src, pattern)))
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
     return f[-1] if f else None
 
 
@@ -33,8 +33,8 @@ def counters(pattern):
         n = r["Kernel_Name"]
         if "k_apply<3, 1024" in n:
             acc["k_apply_L6_fused" if "true" in n else "k_apply_L6_plain"][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        elif "k_cg_update" in n:
-            acc["k_cg_update"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        elif "k_cg_rupdate" in n:
+            acc["k_cg_rupdate"][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
 
 
@@ -43,7 +43,7 @@ for pat in ("pmc_fetch/*/*counter_collection.csv", "pmc_write/*/*counter_collect
             "pmc_sq/*/*counter_collection.csv", "pmc_lds/*/*counter_collection.csv"):
     for k, v in counters(pat).items():
         for c, vals in v.items():
-            if k == "k_cg_update":
+            if k == "k_cg_rupdate":
                 vals = sorted(vals)[-max(1, len(vals) // 4):]      # finest-level launches only
             out.setdefault(k, {})[c] = {"launches": len(vals), "mean": sum(vals) / len(vals)}
 with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
