@@ -1268,7 +1268,8 @@ k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__re
                 const double *__restrict__ scal, double *part0, double *part1)
 {
     __shared__ double red[4];
-    const double alpha = scal[S_C0] / scal[S_C1];
+    // exact convergence (r = 0, e.g. a 1-unknown system after one step) makes p.Ap = 0: stay at the solution
+    const double alpha = scal[S_C1] != 0.0 ? scal[S_C0] / scal[S_C1] : 0.0;
     double rz = 0.0, rr = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
         x[i] += alpha * p[i];
@@ -1292,7 +1293,7 @@ k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__re
 __global__ void __launch_bounds__(256)
 k_coarse_pupdate(CoarseDev A, double *p, const double *__restrict__ z, const double *__restrict__ scal)
 {
-    const double beta = scal[S_C3] / scal[S_C0];
+    const double beta = scal[S_C0] != 0.0 ? scal[S_C3] / scal[S_C0] : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = z[i] + beta * p[i];
 }
