@@ -776,6 +776,10 @@ int hmg_ctx_destroy(hmg_ctx *ctx)
     HMG_TRY
     if (ctx) {
         (void)hipStreamSynchronize(ctx->stream);
+        for (auto &ev : ctx->timer.pool) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
     }
