@@ -97,6 +97,17 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or `make -C homogenization.jl_amd/csrc`).  There is no CPU fallback.")
+        # torch bundles its own HIP runtime.  If the host program uses torch on the GPU (multi-GPU layer, torch
+        # tensors wrapped as level vectors), torch must initialise that runtime BEFORE this library touches HIP;
+        # the other order leaves torch without a visible device.  Only done when torch is already imported.
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is not None:
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except Exception:
+                pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

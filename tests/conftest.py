@@ -8,6 +8,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_sessionstart(session):
+    # torch's bundled HIP runtime has to be initialised before libhmg_hip.so makes its first HIP call
+    # (see homogenization.jl_amd/_lib.py); tests that hand torch tensors to the library rely on it.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: longer CPU test")
