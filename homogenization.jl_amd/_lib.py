@@ -97,9 +97,11 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or `make -C homogenization.jl_amd/csrc`).  There is no CPU fallback.")
-        # torch bundles its own HIP runtime.  If the host program uses torch on the GPU (multi-GPU layer, torch
-        # tensors wrapped as level vectors), torch must initialise that runtime BEFORE this library touches HIP;
-        # the other order leaves torch without a visible device.  Only done when torch is already imported.
+        # torch wheels bundle a HIP runtime with the same SONAME (libamdhip64.so.7) as the system one this
+        # library links.  A process holds one of them: whichever is loaded first.  If the host program uses
+        # torch on the GPU (multi-GPU layer, torch tensors wrapped as level vectors) torch must come first --
+        # then this library runs on torch's runtime and shares its streams; the other order leaves torch
+        # without a usable device.  Only acted upon when torch is already imported.
         import sys
         torch = sys.modules.get("torch")
         if torch is not None:

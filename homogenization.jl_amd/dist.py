@@ -15,6 +15,11 @@ import ctypes
 
 import numpy as np
 
+try:            # torch first: its bundled HIP runtime must be the one the process loads (see _lib.load)
+    import torch  # noqa: F401
+except ImportError:   # single-GPU use does not need torch
+    torch = None
+
 from . import _lib as L
 from . import api, driver
 
