@@ -94,11 +94,9 @@ struct Launch {
 void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
                   const double *x, const double *src, double *out, int use_mask);
 size_t apply_lds_bytes(const LevelDev &lv);
-// Fused CG pass: see k_apply<.., FUSED>.  scal[slot_pap] = sum mult*xin*out, scal[slot_rr] = sum xin*xin
-// (slot_rr < 0: not wanted).  a.scal / a.mult / a.blockpart are filled in by the launcher.
-void launch_apply_fused(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a, int slot_pap,
-                        int slot_rr);
-// the two halves of launch_apply_fused, for callers that split the cells over several launches
+// Fused CG pass, see k_apply<.., FUSED>: the kernel (possibly over a cell list, several launches) leaves
+// per-cell partial sums in mesh.blockpart; the reduce step turns them into scal[slot_pap] = sum mult*xin*out and
+// scal[slot_rr] = sum xin*xin (slot_rr < 0: not wanted).  a.scal / a.mult / a.blockpart are filled in here.
 void launch_apply_fused_kernel(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);
 void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pap, int slot_rr);
 void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);

@@ -531,23 +531,6 @@ void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pa
     check_launch();
 }
 
-void launch_apply_fused(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a, int slot_pap, int slot_rr)
-{
-    a.scal = L.scal;
-    a.mult = mesh.mult;
-    a.blockpart = mesh.blockpart;
-    if (lv.dim == 3)
-        launch_apply_dim<3, true>(L, lv, mesh, a);
-    else
-        launch_apply_dim<2, true>(L, lv, mesh, a);
-    hipLaunchKernelGGL(k_reduce_pairs, dim3(256), dim3(256), 0, L.stream, mesh.blockpart, mesh.ncells, L.partials);
-    check_launch();
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, 256, L.scal, slot_pap);
-    if (slot_rr >= 0)
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, 256, L.scal, slot_rr);
-    check_launch();
-}
-
 // ---------------------------------------------------------------------------------------------
 // interface sum: every shared entity is one contiguous, identically ordered run in each copy
 // ---------------------------------------------------------------------------------------------

@@ -204,10 +204,19 @@ def _oracle_state(c, lev):
     return st
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("which", ["case3", "case2"])
-def test_smoothing_steps(request, which):
-    """smoothing_steps! (CG, duplicate-counting dots) -- ref: src/multigrid.jl:46-71. tol 1e-10 on x, r."""
-    c = request.getfixturevalue(which)
+def test_smoothing_steps(request, oracle, ctx, which, fused):
+    """smoothing_steps! (CG, duplicate-counting dots) -- ref: src/multigrid.jl:46-71. tol 1e-10 on x, r, p.
+    fused=1: p-update / x-update / dot products inside the apply pass; fused=0: one kernel per statement."""
+    if fused:
+        c = request.getfixturevalue(which)
+    else:
+        ctx.set_option("fuse_cg", 0)              # read when a grid is created
+        try:
+            c = Case(oracle, ctx, 3 if which == "case3" else 2, 4, 4, perturb=0.2, seed=17)
+        finally:
+            ctx.set_option("fuse_cg", 1)
     lev = c.levels
     st = _oracle_state(c, lev)
     dst = hmg.LevelState(c.g, lev)
