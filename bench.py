@@ -86,8 +86,9 @@ def main():
     if os.environ.get("HMG_SINGLE_DEVICE") == "1":      # rehearsal of the N>1 path on a 1-GPU box (gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    force_part = os.environ.get("HMG_FORCE_PARTITIONED") == "1"   # rehearsal: partitioned code path on any world size
     dist = None
-    if world > 1:
+    if world > 1 or force_part:
         import torch.distributed as dist
         backend = os.environ.get("HMG_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -102,7 +103,7 @@ def main():
 
     L = args.levels
     w = args.width
-    if world > 1:
+    if world > 1 or force_part:
         from homogenization_jl_amd import dist as hdist
         prob = hdist.partitioned_checkerboard(ctx, w, L, world, rank, seed=0)
         base, cond, implicit, op = prob.base, prob.cond, prob.implicit, prob.op
@@ -119,7 +120,7 @@ def main():
     hmg.broadcast_interfaces(top.x, implicit, L)
     hmg.apply_constraint(top.x, L, implicit)
     hmg.rhs_axi_grad_v(top.b, implicit, driver.random_unit_vec(3))
-    base_level = hmg.BaseLevel(implicit) if world == 1 else prob.base_level()
+    base_level = prob.base_level() if (world > 1 or force_part) else hmg.BaseLevel(implicit)
     ops = [op] * L
 
     def barrier():
@@ -182,7 +183,7 @@ def main():
             "config": {"workload": workload, "cells": ne_total, "nf": nf, "levels": L,
                        "smoothing_steps": args.smoothing_steps, "smoothing_steps_coarse": 2,
                        "coarse_solver": "device Jacobi-PCG rtol 1e-13",
-                       "coarse_iterations_last": base_level.last_iterations() if world == 1 else None,
+                       "coarse_iterations_last": base_level.last_iterations(),
                        "residual_norm_after": rnorm},
             "roofline": {"bound": "hbm",
                          "kernel": "hmg::k_apply<3,1024,7,*> (finest-level operator apply: 3 residual + 6 fused CG passes per V-cycle)",
