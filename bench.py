@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--width", type=int, default=32, help="unit cubes per axis per GPU")
     ap.add_argument("--levels", type=int, default=6, help="refinements + 1")
     ap.add_argument("--smoothing-steps", type=int, default=3)
+    ap.add_argument("--sigma-high", type=float, default=9.0, help="checkerboard contrast: sigma in {1, SIGMA_HIGH}")
     ap.add_argument("--cpu-sample-width", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--apply-threads", type=int, default=None)
@@ -105,12 +106,14 @@ def main():
     w = args.width
     if world > 1 or force_part:
         from homogenization_jl_amd import dist as hdist
-        prob = hdist.partitioned_checkerboard(ctx, w, L, world, rank, seed=0)
+        prob = hdist.partitioned_checkerboard(ctx, w, L, world, rank, seed=0, values=(1.0, args.sigma_high))
         base, cond, implicit, op = prob.base, prob.cond, prob.implicit, prob.op
         workload = f"3D Tet64 checkerboard, {prob.global_shape} unit cubes over {world} GPUs ({w}^3 per GPU), refinements={L - 1}"
     else:
-        base, cond, implicit, op = driver.checkerboard_problem(ctx, hmg.Tet64, w, L, seed=0)
-        workload = f"3D Tet64 checkerboard, {w}^3 unit cubes x 6 tets, refinements={L - 1} (BASELINE config 3)"
+        base, cond, implicit, op = driver.checkerboard_problem(ctx, hmg.Tet64, w, L, seed=0,
+                                                               values=(1.0, args.sigma_high))
+        workload = f"3D Tet64 checkerboard, {w}^3 unit cubes x 6 tets, refinements={L - 1}" + \
+            (" (BASELINE config 3)" if (w, L, args.sigma_high) == (32, 6, 9.0) else "")
     ne_local = implicit.ncells()
     nf = implicit.nf(L)
 
@@ -179,7 +182,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (seeded checkerboard sigma in {1,9}, hashed x0, b = rhs_a.xi.grad(v), lambda=1)",
+            "data": f"synthetic (seeded checkerboard sigma in {{1,{args.sigma_high:g}}}, hashed x0, b = rhs_a.xi.grad(v), lambda=1)",
             "config": {"workload": workload, "cells": ne_total, "nf": nf, "levels": L,
                        "smoothing_steps": args.smoothing_steps, "smoothing_steps_coarse": 2,
                        "coarse_solver": "device Jacobi-PCG rtol 1e-13",

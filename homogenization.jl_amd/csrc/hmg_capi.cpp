@@ -58,7 +58,7 @@ struct DevBuf {
 struct LevelBufs {
     DevBuf<uint64_t> meta;
     DevBuf<uint16_t> lpos, sweep_slot;
-    DevBuf<int> slab_k;
+    DevBuf<int> slab_k, slab_rng;
     int nslab = 0, slab_lds_nodes = 0;
     DevBuf<uint32_t> pos32, pos32w, sweep32;
     DevBuf<double> ctab;
@@ -298,6 +298,43 @@ static void upload_levels(hmg_grid *g)
                 B.nslab = (int)sk.size() - 1;
                 B.slab_lds_nodes = maxn;
                 B.slab_k.upload(sk, s);
+                // slot ranges per slab: inside every entity segment the slots are ordered by plane k, so the
+                // slots of planes [ka, kb) are one contiguous run.  16 segments: 4 corners, 6 edges, 4 faces,
+                // interior (+1 unused).
+                std::vector<std::pair<int, int>> seg;
+                for (int c = 0; c < T.ncorner; ++c) seg.push_back({c, c + 1});
+                for (int e = 0; e < T.nedge; ++e) seg.push_back({T.off_edge + e * T.nei, T.off_edge + (e + 1) * T.nei});
+                for (int f = 0; f < T.nface; ++f) seg.push_back({T.off_face + f * T.nfi, T.off_face + (f + 1) * T.nfi});
+                seg.push_back({T.off_int, T.nf});
+                while (seg.size() < 16) seg.push_back({0, 0});
+                if (seg.size() != 16) throw std::runtime_error("apply slabs: unexpected entity count");
+                auto run = [&](std::pair<int, int> sg, int ka, int kb) {   // slots of the segment with ka <= k < kb
+                    int b = sg.second, e = sg.first;
+                    for (int t = sg.first; t < sg.second; ++t) {
+                        int k = T.slot_ijk[3 * t + 2];
+                        if (k >= ka && k < kb) {
+                            b = std::min(b, t);
+                            e = std::max(e, t + 1);
+                        }
+                    }
+                    if (b >= e) return std::pair<int, int>{0, 0};
+                    for (int t = b; t < e; ++t) {
+                        int k = T.slot_ijk[3 * t + 2];
+                        if (k < ka || k >= kb) throw std::runtime_error("apply slabs: plane range is not contiguous");
+                    }
+                    return std::pair<int, int>{b, e};
+                };
+                std::vector<int> rng((size_t)B.nslab * 64, 0);
+                for (int sl = 0; sl < B.nslab; ++sl)
+                    for (int r = 0; r < 16; ++r) {
+                        auto ld = run(seg[r], sk[sl] - 1, sk[sl + 1] + 1);   // planes held in LDS
+                        auto cp = run(seg[r], sk[sl], sk[sl + 1]);           // planes evaluated
+                        rng[sl * 64 + 2 * r] = ld.first;
+                        rng[sl * 64 + 2 * r + 1] = ld.second;
+                        rng[sl * 64 + 32 + 2 * r] = cp.first;
+                        rng[sl * 64 + 32 + 2 * r + 1] = cp.second;
+                    }
+                B.slab_rng.upload(rng, s);
             }
             B.sweep_slot.upload(T.sweep_slot, s);
             B.ctab.upload(T.ctab, s);
@@ -370,6 +407,7 @@ void set_slab(hmg_grid *g, const LevelDev &lv)
 {
     const LevelBufs &B = *g->lb[lv.level - 1];
     g->md.slab_k = B.slab_k.p;
+    g->md.slab_rng = B.slab_rng.p;
     g->md.nslab = B.nslab;
     g->md.slab_lds_nodes = B.slab_lds_nodes;
 }

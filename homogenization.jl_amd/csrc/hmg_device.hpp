@@ -50,6 +50,7 @@ struct MeshDev {
     double *blockpart;           // 2 per cell: scratch for the fused apply's block sums
     // slab decomposition of the finest level when one cell exceeds the LDS (set per launch by the host)
     const int *slab_k;           // nslab + 1 plane boundaries
+    const int *slab_rng;         // per slab 2 x 16 (begin, end) slot ranges: load phase, compute phase
     int nslab, slab_lds_nodes;
 };
 

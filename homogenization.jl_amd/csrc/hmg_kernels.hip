@@ -352,20 +352,24 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
 
 // Slab variant for cells whose lattice image exceeds the LDS (level 7 in 3D: 374 KiB): the cell is
 // processed in slabs of consecutive k-planes; the LDS holds planes [k0-1, k1] of the lattice image, nodes of
-// planes [k0, k1) are evaluated.  Same tables, same arithmetic as k_apply; not fused, not tuned.
+// planes [k0, k1) are evaluated.  Storage is entity-major with lattice order (k slowest) inside every entity,
+// so the slots of a range of planes are one contiguous run per entity: slab_rng holds, per slab, NR = 16
+// (begin, end) slot ranges for the load phase followed by NR for the compute phase.  Same tables, same
+// arithmetic as k_apply; not fused.
+constexpr int SLAB_NR = 16;
 template <int DIM, int NT>
 __global__ void __launch_bounds__(NT)
 k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a,
-             const int *__restrict__ slab_k, int nslab, int lds_nodes)
+             const int *__restrict__ slab_k, const int *__restrict__ slab_rng, int nslab, int lds_nodes)
 {
     constexpr int NDIR = DIM == 3 ? 15 : 7;
     constexpr int NTERM = DIM == 3 ? 7 : 4;
     extern __shared__ double smem[];
     double *W = smem;
-    double *img = smem + WSZ;                       // lds_nodes doubles: [guard g0 | planes k0-1..k1 | guard g1]
+    double *img = smem + WSZ;                       // lds_nodes doubles: [guard | planes k0-1..k1 | guard g1]
     const int tid = threadIdx.x;
     const int64_t cell = blockIdx.x;
-    const int nf = lv.nf, m = lv.m;
+    const int m = lv.m;
     const int slab_g0 = ((m + 2) * (m + 3)) / 2 + 2;   // reach of the plane-below taps of plane-0 nodes
 
     double s[NTERM];
@@ -381,11 +385,9 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     const uint32_t dm = (a.flags & 1) ? dmask[cell] : 0u;
     const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
     double *oc = a.out + cell * lv.ld;
-    auto plane_off = [&](int k) {   // PO(k) = number of lattice nodes in planes < k (3D), 0 in 2D
-        if (DIM != 3) return 0;
+    auto plane_off = [&](int k) {   // PO(k) = number of lattice nodes in planes < k
         if (k <= 0) return 0;
         if (k > m + 1) k = m + 1;
-        // sum_{q<k} (m-q+1)(m-q+2)/2 = T(m+1) - T(m+1-k), T(n) = n(n+1)(n+2)/6
         const long long n1 = m + 1, n2 = m + 1 - k;
         return (int)((n1 * (n1 + 1) * (n1 + 2) - n2 * (n2 + 1) * (n2 + 2)) / 6);
     };
@@ -393,26 +395,27 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
         const int k0 = slab_k[sl], k1 = slab_k[sl + 1];
         const int lo = plane_off(k0 - 1), hi = plane_off(k1 + 1);   // lattice range held in LDS: [lo, hi)
         double *xs = img + slab_g0 - lo;                            // xs[L] valid for lo - slab_g0 <= L < hi + g1
+        const int *rng = slab_rng + sl * 4 * SLAB_NR;
         __syncthreads();                                            // previous slab fully consumed
-        for (int q = tid; q < lds_nodes; q += NT) img[q] = 0.0;
-        __syncthreads();
-        for (int t = tid; t < nf; t += NT) {
-            const int L = lv.lpos[t];
-            if (L >= lo && L < hi) xs[L] = xc[t];
+        // guards only: every image position in [lo, hi) is overwritten by the load below
+        for (int q = tid; q < slab_g0; q += NT) img[q] = 0.0;
+        for (int q = slab_g0 + (hi - lo) + tid; q < lds_nodes; q += NT) img[q] = 0.0;
+        for (int r = 0; r < SLAB_NR; ++r) {
+            const int b = rng[2 * r], e = rng[2 * r + 1];
+#pragma unroll 4
+            for (int t = b + tid; t < e; t += NT) xs[lv.lpos[t]] = xc[t];
         }
         __syncthreads();
-        for (int t = tid; t < nf; t += NT) {
-            int L, len, A, B, cls, k;
-            decode32w(lv.pos32w[t], m, L, len, A, B, cls, k);
-            if (k < k0 || k >= k1) continue;
-            const double *wr = W + cls * NDIR;
-            double w[NDIR];
-#pragma unroll
-            for (int d = 0; d < NDIR; ++d) w[d] = lds_ld(wr + d);
-            double ctr;
-            double o = (sc ? sc[t] : 0.0) + stencil_eval_v<DIM>(w, xs + L, len, A, B, ctr);
-            if (cls > 0 && ((dm >> (cls - 1)) & 1u)) o = 0.0;
-            oc[t] = o;
+        for (int r = 0; r < SLAB_NR; ++r) {
+            const int b = rng[2 * SLAB_NR + 2 * r], e = rng[2 * SLAB_NR + 2 * r + 1];
+            for (int t = b + tid; t < e; t += NT) {
+                int L, len, A, B, cls, k;
+                decode32w(lv.pos32w[t], m, L, len, A, B, cls, k);
+                double ctr;
+                double o = (sc ? sc[t] : 0.0) + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+                if (cls > 0 && ((dm >> (cls - 1)) & 1u)) o = 0.0;
+                oc[t] = o;
+            }
         }
     }
 }
@@ -464,7 +467,7 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         if (a.cell_list) throw std::runtime_error("cell lists are not supported by the slab apply");
         hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
-                           mesh.slab_k, mesh.nslab, mesh.slab_lds_nodes);
+                           mesh.slab_k, mesh.slab_rng, mesh.nslab, mesh.slab_lds_nodes);
         check_launch();
         return;
     }
