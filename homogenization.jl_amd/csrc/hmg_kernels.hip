@@ -208,14 +208,21 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const int64_t cell = a.cell_list ? (int64_t)a.cell_list[blockIdx.x] : (int64_t)blockIdx.x;
     const int nf = lv.nf;
 
-    double s[NTERM];
-    cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
-    for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
-        const double *c = lv.ctab + (size_t)idx * NTERM;
-        double w = 0.0;
+    // Class weight table of this cell: W[class][dir] = sum_t ctab[class][dir][t] * s[t].  Done by the LAST
+    // waves of the workgroup (their share of the column load below is the smallest), while the others are
+    // already issuing their column loads -- the table's L2 latency then overlaps the HBM latency.
+    if (tid >= NT - 256 || NT <= 256) {
+        double s[NTERM];
+        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
+        const int first = NT <= 256 ? tid : tid - (NT - 256);
+        const int step = NT <= 256 ? NT : 256;
+        for (int idx = first; idx < lv.ncls * NDIR; idx += step) {
+            const double *c = lv.ctab + (size_t)idx * NTERM;
+            double w = 0.0;
 #pragma unroll
-        for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
-        W[idx] = w;
+            for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
+            W[idx] = w;
+        }
     }
     for (int q = tid; q < lv.lds_g0; q += NT) smem[WSZ + q] = 0.0;
     for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
