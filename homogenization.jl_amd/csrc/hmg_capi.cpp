@@ -494,7 +494,8 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     const Launch &L = c->L;
     set_slab(g, lv);
     // algorithmic HBM streams of this launch: x in, out, + src, + x2 (p_old), + xout (p), + xacc (x read and write)
-    const double streams = 2.0 + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) + (a.xacc ? 2.0 : 0.0);
+    const double streams = 1.0 + (a.out ? 1.0 : 0.0) + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) +
+                           (a.xacc ? 2.0 : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
     const int64_t ncut = g->exchange || g->ex_begin ? cut_doubles(g, lv) : 0;
     const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 &&
@@ -514,6 +515,13 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
         if (slot_rr >= 0) scalar_sum(g, slot_rr, 1);
         scalar_sum(g, slot_pap, 1);
     };
+    if (!a.out) {                    // reductions only (dead-tail step of a pre-smoother): nothing to sum or exchange
+        need(fused, "apply without an output vector");
+        launch(nullptr, 0);
+        tr.stop();
+        sums();
+        return;
+    }
     if (!overlap) {
         launch(nullptr, 0);
         tr.stop();
@@ -535,10 +543,13 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     cut_pack(g, lv, a.out, 1);
 }
 
-// keep_p = false skips the reference's last p-update (src/multigrid.jl:68) when its result is dead: inside a
-// V-cycle the pre-smoother's p is overwritten by the post-smoother's `p = r` before anyone can read it.
+// live_tail = false drops the work of the last CG step whose results nobody can read: inside a V-cycle the
+// pre-smoother's r, p and Ap are overwritten (local residual, post-smoother's `p = r`, its first `Ap`) before
+// control returns to the caller, so of step `steps-1` only alpha = rs / p.Ap and x += alpha p are live -- the
+// interface sum of Ap, r -= alpha Ap, r.r and the last p-update (src/multigrid.jl:60-68) are skipped, and the fused
+// kernel does not even store Ap (p.Ap comes from the cell-local products and the multiplicities).
 void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
-            bool keep_p = true)
+            bool live_tail = true)
 {
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
@@ -563,6 +574,7 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
         // The x-update of step i rides with the fused apply of step i+1 (which reads p anyway); the last one
         // is done together with the reference's final p-update.
         for (int i = 0; i < steps; ++i) {
+            const bool dead = !live_tail && i == steps - 1;
             ApplyArgs a{};
             a.alpha = 1.0;
             a.lambda = g->lambda;
@@ -572,21 +584,25 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
             a.xacc = i == 0 ? nullptr : x->d;                             // x += alpha_{i-1} p_{i-1}
             a.a_num = other;                                              // rs_{i-1} (after the swap below)
             a.a_den = S_PAP;                                              // p_{i-1}.Ap_{i-1}: still the old value here
-            a.out = Ap->d;
+            a.out = dead ? nullptr : Ap->d;
             a.s_num = cur;
             a.s_den = other;
             a.flags = 1;
             // (the kernels above read the previous p.Ap from S_PAP; the reduction that overwrites it is enqueued
             //  behind them on the same stream)
             apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1);
+            if (dead) {
+                launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);   // x += (rs / p.Ap) p
+                return;
+            }
             launch_cg_rupdate(L, r->d, Ap->d, n, cur, S_PAP, other);      // alpha = rs / p.Ap
             scalar_sum(g, other, 1);
             std::swap(cur, other);
         }
         if (steps > 0) {
-            // x += alpha_last p (alpha_last = rs_{s-1} / p.Ap: `other` holds rs_{s-1} after the swap) and, if its
-            // result can be observed, the reference's last p-update p = r + (rs_s / rs_{s-1}) p
-            launch_cg_xp_update(L, x->d, p->d, r->d, n, other, S_PAP, cur, other, keep_p ? 1 : 0);
+            // x += alpha_last p (alpha_last = rs_{s-1} / p.Ap: `other` holds rs_{s-1} after the swap) and the
+            // reference's last p-update p = r + (rs_s / rs_{s-1}) p
+            launch_cg_xp_update(L, x->d, p->d, r->d, n, other, S_PAP, cur, other, 1);
         } else {
             launch_copy_dot(L, p->d, r->d, n, cur);
             scalar_sum(g, cur, 1);
@@ -600,6 +616,10 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
         interface_sum(g, lv, Ap->d);
         launch_dot(L, p->d, Ap->d, n, S_PAP);
         scalar_sum(g, S_PAP, 1);
+        if (!live_tail && i == steps - 1) {
+            launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);       // x += (rs / p.Ap) p
+            return;
+        }
         launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs/pAp
         scalar_sum(g, other, 1);
         launch_cg_pupdate(L, p->d, r->d, n, other, cur);                       // beta = rs'/rs
@@ -708,7 +728,7 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     }
     hmg_vec **nxt = st + 5 * (k - 2);
     const Launch &L = g->ctx->L;
-    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*keep_p=*/steps == 0);
+    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false);
     apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                            // local residual
     launch_restrict(L, lev(g, k), lev(g, k - 1), g->md.ncells, cur[2]->d, nxt[1]->d);
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);

@@ -288,7 +288,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const int m = lv.m;
     const uint32_t dm = (a.flags & 1) ? dmask[cell] : 0u;
     const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
-    double *oc = a.out + cell * lv.ld;
+    double *oc = a.out ? a.out + cell * lv.ld : nullptr;   // null: only the reductions of a FUSED pass are wanted
     const int nsurf = lv.off_int;
     uint32_t p0 = tid < nsurf ? lv.pos32[tid] : 0u;
     uint32_t p1 = tid + NT < nsurf ? lv.pos32[tid + NT] : 0u;
@@ -316,7 +316,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         double ctr;
         double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
         if ((dm >> (cls - 1)) & 1u) o = 0.0;
-        oc[t] = o;
+        if (!FUSED || oc) oc[t] = o;
         if (FUSED) {
             const int e = cls - 1;
             const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
@@ -342,7 +342,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             decode32<DIM>(pw, m, L, len, A, B, cls);
             double ctr;
             const double o = sv + stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
-            oc[t] = o;
+            if (!FUSED || oc) oc[t] = o;
             if (FUSED) pap += ctr * o;
         }
     }
