@@ -535,7 +535,8 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     launch_fill(L, g->ex_buf, ncut, 0.0);
     cut_pack(g, lv, a.out, 0);
     if (g->ex_begin(g->ex_user, g->ex_buf, ncut) != 0) throw std::runtime_error("exchange (begin) callback failed");
-    launch(g->md.cells_inner, g->md.ncells_inner);        // overlaps the sum over ranks
+    if (g->md.ncells_inner > 0)                           // (an empty list must not read as "all cells")
+        launch(g->md.cells_inner, g->md.ncells_inner);    // overlaps the sum over ranks
     tr.stop();
     launch_interface_sum(L, lv, g->md, a.out, 2);
     sums();

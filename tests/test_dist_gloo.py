@@ -34,11 +34,18 @@ def _worker(rank, world, port, dim, shape, levels, q):
         O.NTHREADS[0] = 1
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         tag = hmg.Tet64 if dim == 3 else hmg.Tri64
-        origin = tuple(-s / 2.0 for s in shape)
-        base = driver.order_nodes_and_elements_by_magnitude(driver.box_mesh(tag, shape, origin=origin))
-        blocks = hdist.block_shape(world, dim)
-        width = shape[0] // blocks[0]
-        owner = hdist.block_owner(base, blocks, width, origin)
+        if shape == "delaunay":       # unstructured mesh, ragged partition (ownership by a hash of the cell id)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from _meshes import delaunay_mesh
+            dm = delaunay_mesh(O, dim, 70, 13)
+            base = hmg.Mesh(dm.nodes, dm.elements + 1)
+            owner = ((np.arange(dm.nelements()) * 2654435761 >> 7) % world).astype(np.int32)
+        else:
+            origin = tuple(-s / 2.0 for s in shape)
+            base = driver.order_nodes_and_elements_by_magnitude(driver.box_mesh(tag, shape, origin=origin))
+            blocks = hdist.block_shape(world, dim)
+            width = shape[0] // blocks[0]
+            owner = hdist.block_owner(base, blocks, width, origin)
         g = hdist.PartitionedGrid(None, base, levels, owner, rank, world)
         gm = O.Mesh(base.nodes, base.elements - 1)
         lm = O.Mesh(g.base.nodes, g.base.elements - 1)
@@ -145,7 +152,8 @@ def _worker(rank, world, port, dim, shape, levels, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,dim,shape,levels", [(2, 3, (4, 2, 2), 4), (4, 3, (4, 4, 2), 3), (2, 2, (6, 3), 4)])
+@pytest.mark.parametrize("world,dim,shape,levels", [(2, 3, (4, 2, 2), 4), (4, 3, (4, 4, 2), 3), (2, 2, (6, 3), 4),
+                                                      (3, 3, "delaunay", 3), (2, 2, "delaunay", 4)])
 def test_partitioned_interface_sum_matches_serial(world, dim, shape, levels):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -35,7 +35,21 @@ def _worker(rank, world, port, width, levels, overlap, q):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         ctx = hmg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-        prob = hdist.partitioned_checkerboard(ctx, width, levels, world, rank, seed=3)
+        if width == "delaunay":      # unstructured base mesh, ragged 3-way partition (hash of the cell id)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from _meshes import delaunay_mesh
+            dm = delaunay_mesh(O, 3, 70, 13)
+            gbase = hmg.Mesh(dm.nodes, dm.elements + 1)
+            owner = ((np.arange(dm.nelements()) * 2654435761 >> 7) % world).astype(np.int32)
+            prob = hdist.PartitionedProblem()
+            prob.implicit = hdist.PartitionedGrid(ctx, gbase, levels, owner, rank, world)
+            prob.exchange = hdist.Exchange(ctx, prob.implicit)
+            prob.cond = np.random.default_rng(3).choice([1.0, 9.0], size=(dm.nelements(), 3))
+            prob.op = hmg.L2PlusDivAGrad(prob.implicit, 1.0, prob.cond)
+            prob.global_base = gbase
+            prob.base_level = lambda: hmg.BaseLevel(prob.implicit)
+        else:
+            prob = hdist.partitioned_checkerboard(ctx, width, levels, world, rank, seed=3)
         g = prob.implicit
         prob.exchange.set_overlap(g, overlap)
         L = levels
@@ -75,14 +89,14 @@ def _worker(rank, world, port, width, levels, overlap, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_rank_vcycle_matches_serial_oracle(overlap):
+@pytest.mark.parametrize("world,width,levels,overlap", [(2, 4, 4, True), (2, 4, 4, False), (3, "delaunay", 3, True)])
+def test_multi_rank_vcycle_matches_serial_oracle(world, width, levels, overlap):
     """overlap=True: cut-adjacent cells first, asynchronous sum over ranks in flight during the rest."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 4, 4, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, levels, overlap, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]

@@ -29,10 +29,10 @@ def relerr(a, b):
 class Case:
     """A small configuration shared by oracle and device."""
 
-    def __init__(self, O, ctx, dim, n, levels, lam=0.7, perturb=0.0, seed=0, ordered=True):
+    def __init__(self, O, ctx, dim, n, levels, lam=0.7, perturb=0.0, seed=0, ordered=True, mesh=None):
         self.O, self.dim, self.levels, self.lam = O, dim, levels, lam
-        m = O.hypercube(dim, n, origin=(-n / 2.0,) * dim)
-        if ordered:
+        m = mesh if mesh is not None else O.hypercube(dim, n, origin=(-n / 2.0,) * dim)
+        if ordered and mesh is None:
             m = O.order_nodes_and_elements_by_magnitude(m)
         rng = np.random.default_rng(seed)
         if perturb:
@@ -251,6 +251,37 @@ def test_vcycle_matches_oracle(oracle, ctx, which, dim, n, levels):
         assert abs(a - b) <= 1e-8 * a
     assert norms[-1][0] < 0.2 * norms[0][0]                              # multigrid contracts
     assert dbase.last_iterations() > 0
+
+
+@pytest.mark.parametrize("dim,npts,levels", [(3, 60, 4), (2, 80, 5)])
+def test_unstructured_delaunay_mesh(oracle, ctx, dim, npts, levels):
+    """A base mesh that is not a split cube lattice: Delaunay triangulation of random points (edges shared by
+    3..10+ cells, nodes by up to dozens, irregular boundary, cells of very different shape).  Operator apply,
+    interface sum, constraint, smoother and V-cycle against the oracle; same tolerances as the lattice cases."""
+    from _meshes import delaunay_mesh
+    O = oracle
+    mesh = delaunay_mesh(O, dim, npts, 100 + dim)
+    c = Case(O, ctx, dim, 0, levels, lam=1.0, seed=21, mesh=mesh)
+    x = c.rand(levels)
+    y = np.zeros_like(x)
+    O.mul(1.0, mesh, c.ops[-1], x, y)
+    O.apply_constraint(y, levels, c.cons, c.impl)
+    O.broadcast_interfaces(y, c.impl, levels)
+    dx, dy = c.dev(levels, x), c.dev(levels, np.zeros_like(x))
+    hmg.mul(1.0, c.g, c.A, dx, dy)
+    hmg.apply_constraint(dy, levels, c.g)
+    hmg.broadcast_interfaces(dy, c.g, levels)
+    assert relerr(dy.to_host(), y) <= TOL
+    sts = [O.LevelState.create(mesh.nelements(), c.impl.nf(i + 1)) for i in range(levels)]
+    sts[-1] = _oracle_state(c, levels)
+    dsts = [hmg.LevelState(c.g, i + 1) for i in range(levels)]
+    dsts[-1].x.from_host(sts[-1].x); dsts[-1].b.from_host(sts[-1].b)
+    base, dbase = O.make_base_level(mesh, c.sig, 1.0), hmg.BaseLevel(c.g)
+    for cyc in range(2):
+        O.vcycle(c.impl, base, c.ops, sts, levels, 3)
+        hmg.vcycle(c.g, dbase, [c.A] * levels, dsts, levels, 3)
+        assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9, cyc
+        assert relerr(dsts[-1].r.to_host(), sts[-1].r) <= 1e-8, cyc
 
 
 def test_shrink_then_vcycle(oracle, ctx):

@@ -166,9 +166,14 @@ def test_stencil_tables_match_reference_apply(oracle, dim, levels, n):
         assert np.abs(ys[h2s] - y).max() <= 1e-13 * scale
 
 
-def test_mesh_masks_and_lists(oracle):
+@pytest.mark.parametrize("kind", ["lattice", "delaunay"])
+def test_mesh_masks_and_lists(oracle, kind):
     O = oracle
-    m = O.order_nodes_and_elements_by_magnitude(O.hypercube(3, 4, origin=(-2.0, -2.0, -2.0)))
+    if kind == "lattice":
+        m = O.order_nodes_and_elements_by_magnitude(O.hypercube(3, 4, origin=(-2.0, -2.0, -2.0)))
+    else:
+        from _meshes import delaunay_mesh
+        m = delaunay_mesh(O, 3, 80, 7)
     levels = 3
     g = host_grid(m, levels)
     impl = O.ImplicitFineGrid.create(m, levels)
