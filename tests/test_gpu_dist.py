@@ -35,16 +35,17 @@ def _worker(rank, world, port, width, levels, overlap, q):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         ctx = hmg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-        if width == "delaunay":      # unstructured base mesh, ragged 3-way partition (hash of the cell id)
+        if isinstance(width, str):   # "delaunay3" / "delaunay2": unstructured base mesh, ragged partition (hash of the cell id)
+            dim = int(width[-1])
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from _meshes import delaunay_mesh
-            dm = delaunay_mesh(O, 3, 70, 13)
+            dm = delaunay_mesh(O, dim, 70, 13)
             gbase = hmg.Mesh(dm.nodes, dm.elements + 1)
             owner = ((np.arange(dm.nelements()) * 2654435761 >> 7) % world).astype(np.int32)
             prob = hdist.PartitionedProblem()
             prob.implicit = hdist.PartitionedGrid(ctx, gbase, levels, owner, rank, world)
             prob.exchange = hdist.Exchange(ctx, prob.implicit)
-            prob.cond = np.random.default_rng(3).choice([1.0, 9.0], size=(dm.nelements(), 3))
+            prob.cond = np.random.default_rng(3).choice([1.0, 9.0], size=(dm.nelements(), dim))
             prob.op = hmg.L2PlusDivAGrad(prob.implicit, 1.0, prob.cond)
             prob.global_base = gbase
             prob.base_level = lambda: hmg.BaseLevel(prob.implicit)
@@ -89,7 +90,8 @@ def _worker(rank, world, port, width, levels, overlap, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,width,levels,overlap", [(2, 4, 4, True), (2, 4, 4, False), (3, "delaunay", 3, True)])
+@pytest.mark.parametrize("world,width,levels,overlap", [(2, 4, 4, True), (2, 4, 4, False), (3, "delaunay3", 3, True),
+                                                        (2, "delaunay2", 5, True), (2, "delaunay2", 5, False)])
 def test_multi_rank_vcycle_matches_serial_oracle(world, width, levels, overlap):
     """overlap=True: cut-adjacent cells first, asynchronous sum over ranks in flight during the rest."""
     import multiprocessing as mp

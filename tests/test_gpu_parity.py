@@ -413,6 +413,29 @@ def test_level7_cells_larger_than_lds(oracle, ctx):
     assert relerr(db.to_host(), wantb) <= 1e-10
 
 
+def test_level8_triangles_maximum_size(oracle, ctx):
+    """Largest supported 2D level (refinements = 7, m = 128, Nf = 8385, 66 KiB lattice image): apply, smoother
+    and a V-cycle through all 8 levels against the oracle."""
+    O = oracle
+    lev = 8
+    c = Case(O, ctx, 2, 2, lev, lam=1.0, perturb=0.1, seed=17)
+    x, y = c.rand(lev), c.rand(lev)
+    want = y.copy(order="F")
+    O.mul(-0.4, c.mesh, c.ops[lev - 1], x, want)
+    dx, dy = c.dev(lev, x), c.dev(lev, y)
+    hmg.mul(-0.4, c.g, c.A, dx, dy)
+    assert relerr(dy.to_host(), want) <= TOL
+    sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(lev)]
+    sts[-1] = _oracle_state(c, lev)
+    dsts = [hmg.LevelState(c.g, i + 1) for i in range(lev)]
+    dsts[-1].x.from_host(sts[-1].x); dsts[-1].b.from_host(sts[-1].b)
+    base, dbase = O.make_base_level(c.mesh, c.sig, 1.0), hmg.BaseLevel(c.g)
+    O.vcycle(c.impl, base, c.ops, sts, lev, 3)
+    hmg.vcycle(c.g, dbase, [c.A] * lev, dsts, lev, 3)
+    assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9
+    assert relerr(dsts[-1].r.to_host(), sts[-1].r) <= 1e-8
+
+
 def test_single_cell_and_all_dirichlet(oracle, ctx):
     """Edge case: one tetrahedron.  No interfaces, the whole surface is Dirichlet, the level-1 system is empty
     (x1 = 0); apply / smoother / V-cycle must still agree with the oracle."""
