@@ -273,6 +273,9 @@ static void upload_levels(hmg_grid *g)
                     p32w[q] = (i & 127u) | ((j & 127u) << 7) | ((k & 127u) << 14) | ((uint32_t)T.slot_cls[q] << 21);
                 }
                 for (size_t q = 0; q < s32.size(); ++q) s32[q] = pack32(T.sweep_meta[q], 0);
+                // padding read (never used) by k_apply's two-ahead table prefetch: see TABLE_PAD there
+                p32.resize(p32.size() + TABLE_PAD, 0u);
+                s32.resize(s32.size() + TABLE_PAD, 0u);
                 B.pos32.upload(p32, s);
                 B.pos32w.upload(p32w, s);
                 B.sweep32.upload(s32, s);
@@ -336,7 +339,11 @@ static void upload_levels(hmg_grid *g)
                     }
                 B.slab_rng.upload(rng, s);
             }
-            B.sweep_slot.upload(T.sweep_slot, s);
+            {
+                std::vector<uint16_t> ss(T.sweep_slot);
+                ss.resize(ss.size() + TABLE_PAD, (uint16_t)0xffff);
+                B.sweep_slot.upload(ss, s);
+            }
             B.ctab.upload(T.ctab, s);
             B.hier2slot.upload(T.hier2slot, s);
             B.par_a.upload(T.par_a, s);

@@ -6,6 +6,10 @@
 
 namespace hmg {
 
+// pos32 / sweep32 / sweep_slot are followed by this many padding entries (0 / 0 / 0xffff): k_apply prefetches
+// its addressing words two iterations (<= 2 x 1024 threads) ahead of a trip count rounded up to the block size
+constexpr int TABLE_PAD = 3 * 1024;
+
 struct LevelDev {
     int dim, level, m;
     int nf, ld;
@@ -17,12 +21,12 @@ struct LevelDev {
     int nf_coarse;                 // nf of level-1 (0 on level 1)
     const uint64_t *meta;          // [nf]
     const uint16_t *lpos;          // [nf] LDS lattice index of every storage slot
-    const uint16_t *sweep_slot;    // [nsweep] interior sweep in LDS lattice order: storage slot, or 0xffff for
+    const uint16_t *sweep_slot;    // [nsweep + TABLE_PAD] interior sweep in LDS lattice order: storage slot, or 0xffff for
                                    //          the two surface end positions of a row (idle lanes)
     int nsweep;
-    const uint32_t *pos32;         // [nf]     L | j<<16 | k<<22 | cls<<28 (levels whose cell fits the LDS)
+    const uint32_t *pos32;         // [nf + TABLE_PAD] L | j<<16 | k<<22 | cls<<28 (levels whose cell fits the LDS)
     const uint32_t *pos32w;        // [nf]     i | j<<7 | k<<14 | cls<<21  (3D, any level)
-    const uint32_t *sweep32;       // [nsweep] same packing, cls = 0
+    const uint32_t *sweep32;       // [nsweep + TABLE_PAD] same packing, cls = 0
     const double *ctab;            // [ncls*ndir*nterm]
     const int32_t *hier2slot;      // [nf]
     const int32_t *par_a, *par_b;  // [nf]     (level > 1)

@@ -162,7 +162,7 @@ __device__ __forceinline__ void decode32(uint32_t w, int m, int &L, int &len, in
         const int j = (int)((w >> 16) & 63u), k = (int)((w >> 22) & 63u);
         len = m + 1 - j - k;
         const int n = m - k;
-        const int Tk = ((n + 1) * (n + 2)) >> 1;
+        const int Tk = (int)(__umul24((uint32_t)n + 1u, (uint32_t)n + 2u) >> 1);   // n <= 63: full-rate 24-bit multiply
         A = Tk - j;
         B = Tk + n + 2 - j;
     } else {
@@ -290,13 +290,15 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
     double *oc = a.out ? a.out + cell * lv.ld : nullptr;   // null: only the reductions of a FUSED pass are wanted
     const int nsurf = lv.off_int;
-    uint32_t p0 = tid < nsurf ? lv.pos32[tid] : 0u;
-    uint32_t p1 = tid + NT < nsurf ? lv.pos32[tid + NT] : 0u;
+    // (pos32 / sweep32 / sweep_slot carry TABLE_PAD entries of padding -- zero words, slot 0xffff -- so the
+    //  two-ahead prefetch needs no bounds checks and both loops have a wave-uniform trip count)
+    uint32_t p0 = lv.pos32[tid];
+    uint32_t p1 = lv.pos32[tid + NT];
     const int nsw = lv.nsweep;
-    uint32_t q0 = tid < nsw ? lv.sweep32[tid] : 0u;
-    uint32_t q1 = tid + NT < nsw ? lv.sweep32[tid + NT] : 0u;
-    int s0 = tid < nsw ? (int)lv.sweep_slot[tid] : 0xffff;
-    int s1 = tid + NT < nsw ? (int)lv.sweep_slot[tid + NT] : 0xffff;
+    uint32_t q0 = lv.sweep32[tid];
+    uint32_t q1 = lv.sweep32[tid + NT];
+    int s0 = (int)lv.sweep_slot[tid];
+    int s1 = (int)lv.sweep_slot[tid + NT];
     uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
     if (FUSED) {
         const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
@@ -306,36 +308,41 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     __syncthreads();
 
     // surface entities
-    for (int t = tid; t < nsurf; t += NT) {
+    const int nit_surf = (nsurf + NT - 1) / NT;
+    for (int it = 0; it < nit_surf; ++it) {
+        const int t = tid + it * NT;
         const uint32_t pw = p0;
         p0 = p1;
-        p1 = t + 2 * NT < nsurf ? lv.pos32[t + 2 * NT] : 0u;
-        const double sv = sc ? sc[t] : 0.0;
-        int L, len, A, B, cls;
-        decode32<DIM>(pw, m, L, len, A, B, cls);
-        double ctr;
-        double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
-        if ((dm >> (cls - 1)) & 1u) o = 0.0;
-        if (!FUSED || oc) oc[t] = o;
-        if (FUSED) {
-            const int e = cls - 1;
-            const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
-            const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
-            pap += (double)mu * (ctr * o);
+        p1 = lv.pos32[t + 2 * NT];
+        if (t < nsurf) {
+            const double sv = sc ? sc[t] : 0.0;
+            int L, len, A, B, cls;
+            decode32<DIM>(pw, m, L, len, A, B, cls);
+            double ctr;
+            double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+            if ((dm >> (cls - 1)) & 1u) o = 0.0;
+            if (!FUSED || oc) oc[t] = o;
+            if (FUSED) {
+                const int e = cls - 1;
+                const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
+                const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
+                pap += (double)mu * (ctr * o);
+            }
         }
     }
     // cell interior: one weight row for all nodes
     double w0[NDIR];
 #pragma unroll
     for (int d = 0; d < NDIR; ++d) w0[d] = to_sgpr(W[d]);
-    for (int u = tid; u < nsw; u += NT) {
+    const int nit_sweep = (nsw + NT - 1) / NT;
+    for (int it = 0; it < nit_sweep; ++it) {
+        const int u = tid + it * NT;
         const uint32_t pw = q0;
         const int t = s0;
         q0 = q1;
         s0 = s1;
-        const bool more = u + 2 * NT < nsw;
-        q1 = more ? lv.sweep32[u + 2 * NT] : 0u;
-        s1 = more ? (int)lv.sweep_slot[u + 2 * NT] : 0xffff;
+        q1 = lv.sweep32[u + 2 * NT];
+        s1 = (int)lv.sweep_slot[u + 2 * NT];
         if (t != 0xffff) {
             const double sv = sc ? sc[t] : 0.0;
             int L, len, A, B, cls;
