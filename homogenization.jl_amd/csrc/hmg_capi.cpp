@@ -163,6 +163,11 @@ int fail(const std::exception &e)
     {                                \
         return fail(e);              \
     }                                \
+    catch (...)                      \
+    {                                \
+        last_error() = "unknown error"; \
+        return 1;                    \
+    }                                \
     return 0;
 
 void need(bool c, const char *msg)
