@@ -212,7 +212,12 @@ void upload_mesh(hmg_grid *g)
     g->d_dmask.upload(M.dmask, s);
     g->d_dupmask.upload(M.dupmask, s);
     g->d_mult.upload(M.mult, s);
-    if (g->d_blockpart.n < (size_t)M.ncells * 2) g->d_blockpart.alloc((size_t)M.ncells * 2);
+#ifdef HMG_PHASE_TIMING
+    constexpr size_t BP = 8;   // 8 time stamps per workgroup
+#else
+    constexpr size_t BP = 2;
+#endif
+    if (g->d_blockpart.n < (size_t)M.ncells * BP) g->d_blockpart.alloc((size_t)M.ncells * BP);
     MeshDev &d = g->md;
     d.dim = M.dim;
     d.ncells = M.ncells;
@@ -872,6 +877,7 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
     std::string n(name);
     if (n == "apply_threads")
         ctx->L.apply_threads = (int)value;
+
     else if (n == "coarse_maxit")
         ctx->coarse_maxit = (int)value;
     else if (n == "coarse_check")
@@ -1149,6 +1155,18 @@ int hmg_grid_table_f64(const hmg_grid *g, int level, const char *which, double *
         src = &g->lt[level - 1].ctab;
     } else if (w == "coarse_val")
         src = &g->cm.val;
+#ifdef HMG_PHASE_TIMING
+    else if (w == "phase_stamps") {
+        need(g->ctx != nullptr, "no device");
+        *count = (int64_t)g->d_blockpart.n;
+        if (out) {
+            need(cap >= *count, "output buffer too small");
+            HIPCHK(hipStreamSynchronize(g->ctx->stream));
+            HIPCHK(hipMemcpy(out, g->d_blockpart.p, sizeof(double) * g->d_blockpart.n, hipMemcpyDeviceToHost));
+        }
+        return 0;
+    }
+#endif
     else
         throw std::runtime_error("unknown f64 table: " + w);
     *count = (int64_t)src->size();

@@ -195,6 +195,15 @@ __device__ __forceinline__ void decode32w(uint32_t w, int m, int &L, int &len, i
 //   load phase   xin = x + beta*x2 (p = r + beta*p), written back to xout; block sum of xin*xin
 //   epilogue     block sum of mult*xin*out  == this cell's share of dot(p, interface_sum(A p)), because
 //                p is identical in all copies of a shared DOF (src/multigrid.jl:54-68)
+#ifdef HMG_PHASE_TIMING   // dev build (make phase-timing): thread 0 of every workgroup stamps its phases into blockpart
+#define HMG_STAMP(i)                                                                     \
+    do {                                                                                 \
+        if (!FUSED && a.blockpart && tid == 0) a.blockpart[8 * cell + (i)] = (double)wall_clock64(); \
+    } while (0)
+#else
+#define HMG_STAMP(i)
+#endif
+
 template <int DIM, int NT, int SPT, bool FUSED>
 __global__ void __launch_bounds__(NT, NT >= 640 ? 8 : 1)   // 2 x 1024 / 3 x 640 threads per CU need <= 64 VGPRs
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
@@ -207,6 +216,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const int tid = threadIdx.x;
     const int64_t cell = a.cell_list ? (int64_t)a.cell_list[blockIdx.x] : (int64_t)blockIdx.x;
     const int nf = lv.nf;
+    HMG_STAMP(0);
 
     // Class weight table of this cell: W[class][dir] = sum_t ctab[class][dir][t] * s[t].  Done by the LAST
     // waves of the workgroup (their share of the column load below is the smallest), while the others are
@@ -280,6 +290,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
     }
 
+    HMG_STAMP(1);   // column in LDS (this wave)
     // (scheduling fence: keeps the table prefetch below out of the load phase's register budget -- the
     //  1024-thread variants must stay within 64 VGPRs to keep two workgroups resident per CU)
     __builtin_amdgcn_sched_barrier(0);
@@ -305,7 +316,9 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
 #pragma unroll
         for (int q = 0; q < 4; ++q) mq[q] = __builtin_amdgcn_readfirstlane(mp[q]);
     }
+    HMG_STAMP(2);   // tables requested, before the barrier
     __syncthreads();
+    HMG_STAMP(3);
 
     // surface entities
     const int nit_surf = (nsurf + NT - 1) / NT;
@@ -330,6 +343,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             }
         }
     }
+    HMG_STAMP(4);
     // cell interior: one weight row for all nodes
     double w0[NDIR];
 #pragma unroll
@@ -353,6 +367,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             if (FUSED) pap += ctr * o;
         }
     }
+    HMG_STAMP(5);
     if (FUSED) {
         __syncthreads();                     // W / xs no longer read: reuse the front of LDS for the reduction
         const double s_pap = block_sum(pap, smem);
@@ -512,6 +527,9 @@ void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, doub
     a.src = src;
     a.out = out;
     a.flags = (use_mask ? 1 : 0) | (L.apply_mass_only ? 2 : 0);
+#ifdef HMG_PHASE_TIMING
+    a.blockpart = mesh.blockpart;
+#endif
     if (lv.dim == 3)
         launch_apply_dim<3, false>(L, lv, mesh, a);
     else

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Where does a k_apply workgroup spend its life?  Runs the finest-level operator apply from the dev build
+`make -C homogenization.jl_amd/csrc phase-timing` (libhmg_hip_phase_timing.so: thread 0 of every workgroup stamps
+wall_clock64(), 100 MHz, at 6 points) and prints the mean duration of each phase.
+  python tools/phase_timing.py [--mode ap|res] [--width 32] [--levels 6]
+"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import homogenization_jl_amd as hmg
+from homogenization_jl_amd import _lib, driver
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--width", type=int, default=32)
+ap.add_argument("--levels", type=int, default=6)
+ap.add_argument("--mode", default="ap")
+a = ap.parse_args()
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhmg_hip_phase_timing.so")
+ctx = hmg.Context(0)
+L = a.levels
+base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, a.width, L, seed=0)
+x = hmg.DeviceMatrix(g, L).rand(1)
+y = hmg.DeviceMatrix(g, L).rand(2)
+z = hmg.DeviceMatrix(g, L).rand(3)
+for rep in range(3):
+    if a.mode == "res":
+        hmg.apply_ex(-1.0, g, x, y, z, constrain=True)
+    else:
+        hmg.apply_ex(1.0, g, x, None, z, constrain=True)
+ctx.sync()
+st = g.table_f64("phase_stamps").reshape(-1, 8)[: g.ncells(), :6]
+tick = 10.0  # ns per wall_clock64 tick (100 MHz)
+d = np.diff(st, axis=1) * tick / 1e3
+names = ["W table + column load -> LDS", "table prefetch", "barrier wait", "surface loop", "interior loop"]
+print(f"workgroups {st.shape[0]}; kernel span {(st[:, 5].max() - st[:, 0].min()) * tick / 1e6:.3f} ms")
+for i, n in enumerate(names):
+    print(f"  {n:32s} mean {d[:, i].mean():7.2f} us   p10 {np.percentile(d[:, i], 10):7.2f}   p90 {np.percentile(d[:, i], 90):7.2f}")
+life = (st[:, 5] - st[:, 0]) * tick / 1e3
+print(f"  {'workgroup lifetime (stamped)':32s} mean {life.mean():7.2f} us")
+# slot turnaround: sort by start time; with 512 resident workgroups, start[i + 512] - end-ish
+s0 = np.sort(st[:, 0]); e5 = np.sort(st[:, 5])
+nres = 512
+gap = (s0[nres:] - e5[:-nres]) * tick / 1e3
+print(f"  start of workgroup i+{nres} minus end of i (sorted): mean {gap.mean():7.2f} us  (launch + drain overhead per slot)")
+print(f"  per-slot period: {(s0[-1] - s0[0]) * tick / 1e3 / (len(s0) / nres):.2f} us")
