@@ -141,6 +141,10 @@ def main():
         hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
     barrier()
     dt = time.perf_counter() - t0
+    if (world > 1 or force_part) and os.environ.get("HMG_EXCHANGE_STATS") == "1":
+        ex = prob.exchange
+        print(f"[rank {rank}] exchange: {ex.calls} collectives, {ex.doubles * 8 / 1e6:.1f} MB, "
+              f"{ex.seconds:.3f} s host time inside them (warm-up included)", file=sys.stderr, flush=True)
     launches, ms, nbytes = ctx.apply_timing()
     ctx.set_option("time_apply", 0)
     rnorm = hmg.norm_unique(top.r)            # first copies only; summed over ranks by the library

@@ -73,11 +73,17 @@ class Exchange:
         lib = L.load()
         L.check(lib.hmg_ctx_set_scalar_bank(ctx.h, ctypes.c_void_p(self.scal.data_ptr())))
         self.calls = 0
+        self.seconds = 0.0          # host time spent inside the collectives (blocking backends only, e.g. gloo)
+        self.doubles = 0
+        import time as _time
 
         def _sum(tensor, ptr, count):
             off = (ptr - tensor.data_ptr()) // 8
+            t0 = _time.perf_counter()
             self.dist.all_reduce(tensor[off:off + count], group=self.group)
+            self.seconds += _time.perf_counter() - t0
             self.calls += 1
+            self.doubles += count
             return 0
 
         def _exchange(user, ptr, count):
@@ -99,8 +105,11 @@ class Exchange:
         def _begin(user, ptr, count):
             try:
                 off = (ptr - self.buf.data_ptr()) // 8
+                t0 = _time.perf_counter()
                 self._work = self.dist.all_reduce(self.buf[off:off + count], group=self.group, async_op=True)
+                self.seconds += _time.perf_counter() - t0
                 self.calls += 1
+                self.doubles += count
                 return 0
             except Exception as e:
                 print("hmg exchange (begin) failed:", e, flush=True)
@@ -109,7 +118,9 @@ class Exchange:
         def _end(user):
             try:
                 if self._work is not None:
+                    t0 = _time.perf_counter()
                     self._work.wait()          # NCCL: the current stream waits; gloo: the host waits
+                    self.seconds += _time.perf_counter() - t0
                     self._work = None
                 return 0
             except Exception as e:
