@@ -1116,6 +1116,8 @@ int hmg_grid_table_i32(const hmg_grid *g, int level, const char *which, int32_t 
             src = &T.hier2slot;
         else if (w == "slot_ijk")
             src = &T.slot_ijk;
+        else if (w == "ref_cells")
+            src = &T.ref_cells;
         else if (w == "par_a")
             src = &T.par_a;
         else if (w == "par_b")

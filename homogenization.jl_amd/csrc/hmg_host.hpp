@@ -45,6 +45,11 @@ struct LevelTables {
     int ncls = 0, ndir = 0, nterm = 0;
     std::vector<double> ctab;
 
+    // cells of the refined reference simplex (Kuhn sub-simplices), dim+1 hierarchical node ids each; the set of
+    // cells equals refined_element(level) of the reference (src/multilevel_reference.jl:41-61), the order is the
+    // lattice enumeration, not the red-refinement order (used for export only)
+    std::vector<int32_t> ref_cells;
+
     // dphi[3*slot + a] = int d phi_slot / d x_a over the refined reference simplex
     // (ref: src/examples/homogenized_coefficients.jl:407-442, partial_derivatives_functionals)
     std::vector<double> dphi;

@@ -377,6 +377,7 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
                         simplex_gradients(dim, m, V, g, vol);
                         int sl[4];
                         for (int v = 0; v <= dim; ++v) sl[v] = slot_at[lat.idx(V[v][0], V[v][1], V[v][2])];
+                        for (int v = 0; v <= dim; ++v) T.ref_cells.push_back(T.slot2hier[sl[v]]);
                         for (int u = 0; u <= dim; ++u)
                             for (int a = 0; a < dim; ++a) T.dphi[(size_t)sl[u] * 3 + a] += vol * g[a][u];
                         for (int u = 0; u <= dim; ++u)

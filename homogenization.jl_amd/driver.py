@@ -8,10 +8,11 @@ vector on the host.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 
-from . import api
+from . import api, vtk
 from .api import Mesh, Tet64, Tri64
 
 _CUBE_TETS = ((0, 1, 2, 6), (0, 1, 4, 6), (1, 3, 2, 6), (1, 3, 6, 7), (1, 5, 4, 6), (1, 5, 6, 7))
@@ -148,12 +149,14 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     (src/examples/homogenized_coefficients.jl:174-343) with every level-vector operation on the device.
 
     Differences to the reference, all explicit: the coefficient field and the initial guess are seeded
-    (`seed`, or passed in as `sigma_grid` / `x0`) instead of drawn from the global RNG; `save` (VTK export) is
-    not supported; the level-1 solve is the library's PCG; a domain shrink keeps the level vectors in place
+    (`seed`, or passed in as `sigma_grid` / `x0`) instead of drawn from the global RNG; `save` (a level, as in the
+    reference: checkerboard.vtu + one ahom_k.vtu per outer step, see vtk.py) may also be a (level, directory) pair;
+    the level-1 solve is the library's PCG; a domain shrink keeps the level vectors in place
     (their columns are a prefix) instead of copying slices.  Returns (sigma, history) where history holds
     (k, cycle, norm(r), sigma + dsigma, |dsigma - dsigma_prev|) -- the three quantities the reference logs."""
-    if save is not None:
-        raise NotImplementedError("VTK export (`save`) is outside the hot path")
+    save_dir = "."
+    if isinstance(save, tuple):
+        save, save_dir = save
     dim = api._dim_of(eltype)
     own_ctx = ctx is None
     if own_ctx:
@@ -169,6 +172,10 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
         sigma_grid = generate_conductivity(dim, width, seed, values)
     cond = conductivity_per_element(base, sigma_grid, (total_radius + 1.0,) * dim)
     total_grids = refinements + 1
+    if save is not None:
+        if not 1 <= save <= total_grids:
+            raise ValueError("save must be a level in 1..refinements+1")
+        vtk.export_domain(base, cond, os.path.join(save_dir, "checkerboard"))
     implicit = api.ImplicitFineGrid(ctx, base, total_grids)
     op = api.L2PlusDivAGrad(implicit, lam, cond)
     ops = [op] * total_grids
@@ -204,6 +211,8 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
                 break
             dsig_prev = dsig
         sigma += dsig
+        if save is not None:                             # ref: ...homogenized_coefficients.jl:303
+            vtk.export_unknown(implicit, top.x, k, save, os.path.join(save_dir, f"ahom_{k}"))
         lam /= 2
         box_radius = compute_box_radius(k + 1, n)
         boundary_layer = compute_boundary_layer(lam, n)

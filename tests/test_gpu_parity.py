@@ -385,6 +385,26 @@ def test_checkerboard_homogenization_matches_oracle_driver(oracle, ctx, dim, n, 
         assert abs(a[3] - b[3]) <= 1e-8                              # sigma + dsigma per cycle
 
 
+def test_driver_save_writes_vtk(ctx, tmp_path):
+    """`save = level` (src/examples/homogenized_coefficients.jl:219,303): checkerboard.vtu + one ahom_k.vtu per outer
+    step on the full grid of that level; sigma is unaffected."""
+    from homogenization_jl_amd import driver, vtk
+    sig0, hist0 = driver.checkerboard_homogenization(1, hmg.Tri64, refinements=2, tolerance=1e-3, ctx=ctx)
+    sig1, hist1 = driver.checkerboard_homogenization(1, hmg.Tri64, refinements=2, tolerance=1e-3, ctx=ctx,
+                                                     save=(2, str(tmp_path)))
+    assert sig0 == sig1 and len(hist0) == len(hist1)
+    dom = vtk.read_vtu(str(tmp_path / "checkerboard.vtu"))
+    ne = dom["offsets"].size
+    assert dom["cell_data"]["a"].shape == (ne, 2)
+    outer = sorted({h[0] for h in hist1})
+    for k in outer:
+        out = vtk.read_vtu(str(tmp_path / f"ahom_{k}.vtu"))
+        assert out["point_data"]["v"].size == out["points"].shape[0]
+        assert out["points"].shape[0] % 6 == 0                          # Nf(level 2) = 6 nodes per coarse triangle
+        assert out["points"].shape[0] // 6 <= ne
+        assert np.isfinite(out["point_data"]["v"]).all()
+
+
 def test_level7_cells_larger_than_lds(oracle, ctx):
     """refinements = 6: Nf = 47 905 (374 KiB per cell) does not fit the 160 KiB LDS; the slab-wise apply and the
     unfused smoother take over.  ref: src/apply_local_operators.jl:85-133, src/multigrid.jl:46-71"""

@@ -315,3 +315,37 @@ def test_single_cell_mesh_tables():
     assert g.table_i32("dmask")[0] == (1 << 14) - 1 and g.table_i32("dupmask")[0] == 0
     assert g.interior_nodes().size == 0
     assert set(g.table_i32("mult")[:14]) == {1}
+
+
+@pytest.mark.parametrize("dim,level", [(2, 3), (3, 3)])
+def test_vtk_export_of_a_level(oracle, tmp_path, dim, level):
+    """`save`: construct_full_grid (src/implicit_fine_grid.jl:41-78) and the .vtu files of export_domain /
+    export_unknown (src/examples/homogenized_coefficients.jl:69-87), read back with a minimal parser."""
+    from homogenization_jl_amd import vtk
+    O = oracle
+    m = small_mesh(O, dim, 2, perturb=0.2, seed=3)
+    g = host_grid(m, 4)
+    nodes, cells = vtk.construct_full_grid(g, level)
+    impl = O.ImplicitFineGrid.create(m, 4)
+    ref = impl.reference.levels[level - 1]
+    nf, ne = ref.nodes.shape[0], m.nelements()
+    assert nodes.shape == (nf * ne, dim) and cells.shape == (ref.elements.shape[0] * ne, dim + 1)
+    for e in (0, ne - 1):
+        X = m.nodes[m.elements[e]]
+        want = X[0] + ref.nodes @ (X[1:] - X[0])
+        np.testing.assert_allclose(nodes[e * nf:(e + 1) * nf], want, atol=1e-14)
+        got = {tuple(sorted(c)) for c in (cells[e * ref.elements.shape[0]:(e + 1) * ref.elements.shape[0]] - e * nf).tolist()}
+        assert got == {tuple(sorted(c)) for c in ref.elements.tolist()}
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((impl.nf(4), ne))
+    path = vtk.export_unknown(g, x, 2, level, str(tmp_path / "ahom_2"))
+    back = vtk.read_vtu(path)
+    np.testing.assert_array_equal(back["points"][:, :dim], nodes)
+    np.testing.assert_array_equal(back["connectivity"].reshape(-1, dim + 1), cells)
+    np.testing.assert_array_equal(back["offsets"], (dim + 1) * np.arange(1, cells.shape[0] + 1))
+    assert set(back["types"].tolist()) == {5 if dim == 2 else 10}
+    np.testing.assert_array_equal(back["point_data"]["v"], x[:nf, :].T.ravel())
+    sig = rng.choice([1.0, 9.0], size=(ne, dim))
+    back = vtk.read_vtu(vtk.export_domain(g.base, sig, str(tmp_path / "checkerboard")))
+    np.testing.assert_array_equal(back["cell_data"]["a"], sig)
+    assert back["connectivity"].reshape(-1, dim + 1).tolist() == m.elements.tolist()
