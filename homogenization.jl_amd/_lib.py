@@ -32,6 +32,7 @@ SIGNATURES = {
     "hmg_ctx_apply_timing": (c_int, [vp, p_i64, p_f64, p_f64]),
     "hmg_rhs_axi_grad": (c_int, [vp, p_f64, vp]),
     "hmg_next_rhs": (c_int, [vp, vp, vp]),
+    "hmg_local_rhs": (c_int, [vp, vp]),
     "hmg_integrate": (c_int, [vp, c_int, vp, vp, c_i64, p_f64, p_f64]),
     "hmg_grid_create": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, pp]),
     "hmg_grid_destroy": (c_int, [vp]),

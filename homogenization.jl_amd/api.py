@@ -335,6 +335,11 @@ def rhs_axi_grad_v(b: DeviceMatrix, implicit: ImplicitFineGrid, xi):
     L.check(L.load().hmg_rhs_axi_grad(implicit.h, xi.ctypes.data_as(L.p_f64), b.h))
 
 
+def local_rhs(b: DeviceMatrix, implicit: ImplicitFineGrid):
+    """local_rhs!(b, implicit): unit load, b[:, e] = |det J_e| * int phi (src/implicit_fine_grid.jl:391-409)"""
+    L.check(L.load().hmg_local_rhs(implicit.h, b.h))
+
+
 def next_rhs(b: DeviceMatrix, x: DeviceMatrix, implicit: ImplicitFineGrid):
     """next_rhs!: b = lam*|J|*M*x  (src/examples/homogenized_coefficients.jl:695-713)"""
     L.check(L.load().hmg_next_rhs(implicit.h, x.h, b.h))

@@ -1157,6 +1157,10 @@ int hmg_grid_table_f64(const hmg_grid *g, int level, const char *which, double *
         src = &g->lt[level - 1].ctab;
     } else if (w == "coarse_val")
         src = &g->cm.val;
+    else if (w == "load") {
+        need(level >= 1 && level <= g->nlevels, "level out of range");
+        src = &g->lt[level - 1].load;
+    }
 #ifdef HMG_PHASE_TIMING
     else if (w == "phase_stamps") {
         need(g->ctx != nullptr, "no device");
@@ -1472,6 +1476,28 @@ int hmg_rhs_axi_grad(hmg_grid *g, const double *xi, hmg_vec *b)
     DevBuf<double> d;
     d.upload(pv, g->ctx->stream);
     launch_rhs_dphi(g->ctx->L, lev(g, b->level), M.ncells, d.p, b->d);
+    HIPCHK(hipStreamSynchronize(g->ctx->stream));
+    HMG_END
+}
+
+int hmg_local_rhs(hmg_grid *g, hmg_vec *b)
+{
+    HMG_TRY
+    need(g && b, "null argument");
+    check_vec(g, b->level, b, "b");
+    const MeshTables &M = g->cur();
+    LevelDev lv = lev(g, b->level);
+    const LevelTables &T = g->lt[b->level - 1];
+    // b[:, e] = (int phi over the refined reference simplex) * |det J_e|   (ref: src/implicit_fine_grid.jl:391-409);
+    // evaluated by the d.p kernel of the other right-hand sides with d = (load, 0, 0), p = (|det J|, 0, 0)
+    std::vector<double> tab((size_t)T.nf * 3, 0.0), pv((size_t)M.ncells * 3, 0.0);
+    for (int t = 0; t < T.nf; ++t) tab[(size_t)t * 3] = T.load[t];
+    for (int64_t c = 0; c < M.ncells; ++c) pv[(size_t)c * 3] = M.detj[c];
+    DevBuf<double> dt, dp;
+    dt.upload(tab, g->ctx->stream);
+    dp.upload(pv, g->ctx->stream);
+    lv.dphi = dt.p;
+    launch_rhs_dphi(g->ctx->L, lv, M.ncells, dp.p, b->d);
     HIPCHK(hipStreamSynchronize(g->ctx->stream));
     HMG_END
 }

@@ -50,6 +50,9 @@ struct LevelTables {
     // lattice enumeration, not the red-refinement order (used for export only)
     std::vector<int32_t> ref_cells;
 
+    // load[slot] = int phi_slot over the refined reference simplex (assemble_vector(fine, identity), src/assembly.jl:121-155)
+    std::vector<double> load;
+
     // dphi[3*slot + a] = int d phi_slot / d x_a over the refined reference simplex
     // (ref: src/examples/homogenized_coefficients.jl:407-442, partial_derivatives_functionals)
     std::vector<double> dphi;

@@ -346,6 +346,7 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
         T.nterm = nterm;
         std::vector<double> rows((size_t)nf * ndir * nterm, 0.0);
         T.dphi.assign((size_t)nf * 3, 0.0);
+        T.load.assign((size_t)nf, 0.0);
         std::vector<int32_t> slot_at((size_t)(m + 1) * (m + 1) * (dim == 3 ? m + 1 : 1), -1);
         for (int s = 0; s < nf; ++s)
             slot_at[lat.idx(T.slot_ijk[3 * s], T.slot_ijk[3 * s + 1], T.slot_ijk[3 * s + 2])] = s;
@@ -380,6 +381,7 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
                         for (int v = 0; v <= dim; ++v) T.ref_cells.push_back(T.slot2hier[sl[v]]);
                         for (int u = 0; u <= dim; ++u)
                             for (int a = 0; a < dim; ++a) T.dphi[(size_t)sl[u] * 3 + a] += vol * g[a][u];
+                        for (int u = 0; u <= dim; ++u) T.load[sl[u]] += vol / (dim + 1);
                         for (int u = 0; u <= dim; ++u)
                             for (int v = 0; v <= dim; ++v) {
                                 int d = dir_index(dim, V[v][0] - V[u][0], V[v][1] - V[u][1], V[v][2] - V[u][2]);

@@ -230,3 +230,45 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     if own_ctx:
         ctx.sync()
     return sigma, history
+
+
+def checkerboard_hypercube_multigrid(n: int, eltype=Tet64, refinements: int = 2, max_cycles: int = 5, save=None, *,
+                                     ctx=None, seed: int = 1, sigma_grid=None, x0=None):
+    """checkerboard_hypercube_multigrid(n, elementtype, refinements, max_cycles, save) -> residual norms
+    (src/examples/homogenized_coefficients.jl:509-571): -div(a grad u) = 1 with zero Dirichlet data (lambda = 0),
+    `max_cycles` V-cycles with 3 smoothing steps; `refinements` is the number of grids.  Seeded like the other
+    driver; `save` = level (or (level, directory)) writes checkerboard_full_<refinements>.vtu with point data "x".
+    Returns (rs, state of the finest level, implicit grid)."""
+    dim = api._dim_of(eltype)
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = api.Context(0)
+    base = hypercube(eltype, n)
+    if sigma_grid is None:
+        sigma_grid = generate_conductivity(dim, n, seed)
+    cond = conductivity_per_element(base, sigma_grid, (0.0,) * dim)
+    implicit = api.ImplicitFineGrid(ctx, base, refinements)
+    op = api.L2PlusDivAGrad(implicit, 0.0, cond)
+    base_level = api.BaseLevel(implicit)
+    states = [api.LevelState(implicit, i + 1) for i in range(refinements)]
+    top = states[-1]
+    if x0 is None:
+        top.x.rand(seed + 1)
+    else:
+        top.x.from_host(x0)
+    api.broadcast_interfaces(top.x, implicit, refinements)
+    api.apply_constraint(top.x, refinements, implicit)
+    api.local_rhs(top.b, implicit)
+    rs = []
+    for _ in range(max_cycles):
+        api.vcycle(implicit, base_level, [op] * refinements, states, refinements, 3)
+        rs.append(api.norm_unique(top.r))
+    if save is not None:
+        save_dir = "."
+        if isinstance(save, tuple):
+            save, save_dir = save
+        vtk.export_unknown(implicit, top.x, 0, save, os.path.join(save_dir, f"checkerboard_full_{refinements}"),
+                           field="x")
+    if own_ctx:
+        ctx.sync()
+    return rs, top, implicit

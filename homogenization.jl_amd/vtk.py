@@ -107,11 +107,11 @@ def export_domain(base, cond, name="checkerboard"):
     return write_vtu(name, base.nodes, base.elements - 1, cell_data={"a": np.asarray(cond, dtype=np.float64)})
 
 
-def export_unknown(implicit, x, k: int, level: int, name=None):
+def export_unknown(implicit, x, k: int, level: int, name=None, field="v"):
     """ref: src/examples/homogenized_coefficients.jl:81-87 -- point data "v" = x[1:nnodes(level), :][:] on the full
     grid of `level`.  `x` is a DeviceMatrix of the finest level or a host (Nf, Ne) array in hierarchical order."""
     nodes, cells = construct_full_grid(implicit, level)
     xh = x.to_host() if hasattr(x, "to_host") else np.asarray(x)
     nfl = implicit.nf(level)
     v = np.ascontiguousarray(xh[:nfl, :].T).ravel()
-    return write_vtu(name or f"ahom_{k}", nodes, cells, point_data={"v": v})
+    return write_vtu(name or f"ahom_{k}", nodes, cells, point_data={field: v})

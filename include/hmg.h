@@ -113,6 +113,9 @@ int hmg_scatter_base(hmg_grid *grid, const double *host_u, hmg_vec *v1);
 /* ---- driver right-hand sides (run once per outer step) --------------------------------- */
 /* rhs_a xi grad v!(b, dphis, implicit, sigmas, xi)   (src/examples/homogenized_coefficients.jl:449-474) */
 int hmg_rhs_axi_grad(hmg_grid *grid, const double *xi /* dim */, hmg_vec *b);
+/* local_rhs!(b, implicit): b[:, e] = |det J_e| * int phi over the refined reference cell (unit load;
+ * src/implicit_fine_grid.jl:391-409, used by checkerboard_hypercube_multigrid, ...homogenized_coefficients.jl:543) */
+int hmg_local_rhs(hmg_grid *grid, hmg_vec *b);
 /* integrate_first_term (mode 0, needs xi), integrate_terms (mode 1, needs vprev), integrate_area (mode 2) over
  * the first ncells_subset cells   (src/examples/homogenized_coefficients.jl:592-689) */
 int hmg_integrate(hmg_grid *grid, int mode, hmg_vec *v, hmg_vec *vprev, int64_t ncells_subset, const double *xi,

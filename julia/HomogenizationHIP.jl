@@ -8,7 +8,7 @@ module HomogenizationHIP
 using Homogenization
 import Homogenization: mul!, local_residual!, apply_constraint!, broadcast_interfaces!,
        zero_out_all_but_one!, restrict_to!, interpolate_and_sum_to!, smoothing_steps!, vcycle!,
-       copy_to_base!, distribute!, LevelState, ImplicitFineGrid, L2PlusDivAGrad
+       copy_to_base!, distribute!, local_rhs!, LevelState, ImplicitFineGrid, L2PlusDivAGrad
 import LinearAlgebra: dot, axpy!
 
 const LIB = get(ENV, "HMG_LIB", "libhmg_hip.so")
@@ -107,5 +107,12 @@ function vcycle!(implicit, base, ops, levels::Vector{LevelState{Float64,HipMatri
     hs = Ptr{Cvoid}[getfield(l, f).h for l in levels for f in (:x, :b, :r, :p, :Ap)]
     check(ccall((:hmg_vcycle, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Ptr{Cvoid}}), levels[1].x.grid.h, k, steps, 2, hs))
 end
+
+# driver right-hand sides (src/implicit_fine_grid.jl:391, src/examples/homogenized_coefficients.jl:449,695)
+local_rhs!(b::HipMatrix, implicit) = check(ccall((:hmg_local_rhs, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), b.grid.h, b.h))
+rhs_aξ∇v!(b::HipMatrix, ∂ϕs, implicit, σs, ξ) =
+    check(ccall((:hmg_rhs_axi_grad, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), b.grid.h, collect(Float64, ξ), b.h))
+next_rhs!(b::HipMatrix, x::HipMatrix, implicit, ops) =
+    check(ccall((:hmg_next_rhs, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), b.grid.h, x.h, b.h))
 
 end # module

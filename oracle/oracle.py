@@ -340,6 +340,20 @@ def assemble_checkerboard(mesh: Mesh, sigmas, lam=1.0):
     return A
 
 
+def assemble_vector(mesh: Mesh, functional=lambda v: v):
+    """b[i] = int functional(phi_i), 4-pt / 3-pt quadrature.  ref: src/assembly.jl:121-155"""
+    dim = mesh.dim
+    _, _, det = cell_geometry(mesh)
+    _, w = quad_rule(dim)
+    phi = basis_values(dim)
+    b_local = np.zeros(dim + 1)
+    for q in range(len(w)):                       # qp outer, i inner: the reference's accumulation order
+        b_local += w[q] * functional(phi[q])
+    b = np.zeros(mesh.nnodes())
+    np.add.at(b, mesh.elements.reshape(-1), (b_local[None, :] * det[:, None]).reshape(-1))
+    return b
+
+
 def partial_derivatives_functionals(mesh: Mesh):
     """bs[node, j] = int d phi_node / d x_j. ref: ...homogenized_coefficients.jl:407-442"""
     dim = mesh.dim
@@ -1034,6 +1048,16 @@ class _SpluSolver:
         return self.lu.solve(b)
 
 
+def local_rhs(b, implicit: ImplicitFineGrid):
+    """b[:, e] = assemble_vector(fine reference mesh, identity) * |det J_e|.  ref: src/implicit_fine_grid.jl:391-409"""
+    fine = implicit.reference.levels[-1]
+    assert b.shape == (fine.nnodes(), implicit.base.nelements())
+    b_ref = assemble_vector(fine)
+    _, _, det = cell_geometry(implicit.base)
+    b[...] = b_ref[:, None] * det[None, :]
+    return b
+
+
 def make_base_level(base: Mesh, sigmas, lam):
     """ref: ...homogenized_coefficients.jl:259-261"""
     interior = list_interior_nodes(base)
@@ -1117,3 +1141,31 @@ def checkerboard_homogenization(n=4, dim=2, refinements=2, smoothing_steps_=3, t
         ops = [L2PlusDivAGrad(d, m, constraint, lam, cond) for d, m in zip(diff_terms, mass_terms)]
         next_rhs(top.b, top.x, implicit, mass_terms[-1], lam)
     return sigma, history
+
+
+def checkerboard_hypercube_multigrid(n, dim=3, refinements=2, max_cycles=5, seed=1, sigma_grid=None, x0=None):
+    """Solve -div(a grad u) = 1, u = 0 on the boundary, with `max_cycles` V-cycles (lambda = 0); returns the residual
+    norms and the final state.  `refinements` is the number of grids, as in the reference.
+    ref: ...homogenized_coefficients.jl:509-571 (VTK output left to the caller; RNG seeded here)."""
+    rng = np.random.default_rng(seed)
+    base = hypercube(dim, n)
+    if sigma_grid is None:
+        sigma_grid = np.where(rng.random((n,) * dim + (dim,)) < 0.5, 1.0, 9.0)
+    cond = conductivity_per_element(base, sigma_grid, (0.0,) * dim)
+    base_level = make_base_level(base, cond, 0.0)
+    implicit = ImplicitFineGrid.create(base, refinements)
+    constraint = ZeroDirichletConstraint(*list_boundary_nodes_edges_faces(base))
+    ops = [L2PlusDivAGrad(build_local_diffusion_operators(m), mass_matrix(m), constraint, 0.0, cond)
+           for m in implicit.reference.levels]
+    states = [LevelState.create(base.nelements(), implicit.nf(i + 1)) for i in range(refinements)]
+    top = states[-1]
+    top.x[...] = rng.random(top.x.shape) if x0 is None else x0
+    broadcast_interfaces(top.x, implicit, refinements)
+    apply_constraint(top.x, refinements, constraint, implicit)
+    local_rhs(top.b, implicit)
+    rs = []
+    for _ in range(max_cycles):
+        vcycle(implicit, base_level, ops, states, refinements, 3)
+        zero_out_all_but_one(top.r, implicit, refinements)
+        rs.append(float(np.linalg.norm(top.r)))
+    return rs, top, implicit, base, cond

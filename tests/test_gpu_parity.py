@@ -385,6 +385,30 @@ def test_checkerboard_homogenization_matches_oracle_driver(oracle, ctx, dim, n, 
         assert abs(a[3] - b[3]) <= 1e-8                              # sigma + dsigma per cycle
 
 
+@pytest.mark.parametrize("dim,n,grids", [(3, 3, 3), (2, 5, 4)])
+def test_hypercube_multigrid_driver_matches_oracle(oracle, ctx, tmp_path, dim, n, grids):
+    """checkerboard_hypercube_multigrid (...homogenized_coefficients.jl:509-571): local_rhs!, lambda = 0, residual norm
+    per V-cycle and the final x against the oracle driver; the VTK file of the finest level holds x."""
+    from homogenization_jl_amd import driver, vtk
+    O = oracle
+    tag = hmg.Tet64 if dim == 3 else hmg.Tri64
+    sgrid = driver.generate_conductivity(dim, n, 7)
+    nf = O.ImplicitFineGrid.create(O.hypercube(dim, 1), grids).nf(grids)
+    x0 = hmg.host_random((nf, (6 if dim == 3 else 2) * n ** dim), 5)
+    rs_o, top_o, impl_o, base_o, _ = O.checkerboard_hypercube_multigrid(n, dim=dim, refinements=grids, max_cycles=4,
+                                                                       sigma_grid=sgrid, x0=x0)
+    b_o = top_o.b.copy()
+    rs_d, top_d, g = driver.checkerboard_hypercube_multigrid(n, tag, grids, 4, save=(grids, str(tmp_path)), ctx=ctx,
+                                                             sigma_grid=sgrid, x0=x0)
+    assert relerr(top_d.b.to_host(), b_o) <= TOL                        # local_rhs!
+    for a, b in zip(rs_o, rs_d):
+        assert abs(a - b) <= 1e-8 * a
+    assert relerr(top_d.x.to_host(), top_o.x) <= 1e-9
+    out = vtk.read_vtu(str(tmp_path / f"checkerboard_full_{grids}.vtu"))
+    np.testing.assert_array_equal(out["point_data"]["x"], top_d.x.to_host().T.ravel())
+    np.testing.assert_allclose(out["points"][:, :dim], impl_o.construct_full_grid(grids).reshape(-1, dim), atol=1e-14)
+
+
 def test_driver_save_writes_vtk(ctx, tmp_path):
     """`save = level` (src/examples/homogenized_coefficients.jl:219,303): checkerboard.vtu + one ahom_k.vtu per outer
     step on the full grid of that level; sigma is unaffected."""

@@ -349,3 +349,15 @@ def test_vtk_export_of_a_level(oracle, tmp_path, dim, level):
     back = vtk.read_vtu(vtk.export_domain(g.base, sig, str(tmp_path / "checkerboard")))
     np.testing.assert_array_equal(back["cell_data"]["a"], sig)
     assert back["connectivity"].reshape(-1, dim + 1).tolist() == m.elements.tolist()
+
+
+@pytest.mark.parametrize("dim,levels", [(3, 5), (2, 6)])
+def test_unit_load_table(oracle, dim, levels):
+    """int phi over the refined reference cell == assemble_vector(refined_mesh, identity) (src/assembly.jl:121-155)."""
+    O = oracle
+    g = host_grid(small_mesh(O, dim, 1), levels)
+    impl = O.ImplicitFineGrid.create(small_mesh(O, dim, 1), levels)
+    for lev in range(1, levels + 1):
+        want = O.assemble_vector(impl.reference.levels[lev - 1])
+        got = g.table_f64("load", lev)[g.table_i32("hier2slot", lev)]
+        np.testing.assert_allclose(got, want, rtol=1e-13)

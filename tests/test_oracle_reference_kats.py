@@ -171,3 +171,35 @@ def test_documented_grid_size_example(oracle):
     implicit = O.ImplicitFineGrid.create(base, 3)
     assert (base.nnodes(), base.nelements(), implicit.nf(3)) == (1089, 2048, 15)
     assert implicit.nf(3) * base.nelements() == 30720
+
+
+@pytest.mark.parametrize("dim,n,grids", [(2, 3, 4), (3, 2, 3)])
+def test_multigrid_converges_to_direct_solution(oracle, dim, n, grids):
+    """Independent second oracle (recipe of checkerboard_hypercube_full, ...homogenized_coefficients.jl:729-759):
+    explicit refine_uniformly + assemble_checkerboard + sparse direct solve of -div(a grad u) = 1; the V-cycle
+    iteration of checkerboard_hypercube_multigrid (:509-571: local_rhs!, lambda = 0) must converge to it."""
+    import scipy.sparse.linalg as spla
+    O = oracle
+    rs, top, implicit, base, cond = O.checkerboard_hypercube_multigrid(n, dim=dim, refinements=grids, max_cycles=40, seed=4)
+    assert rs[-1] < 1e-9 * rs[0]
+    fine = O.refine_uniformly(base, times=grids - 1)
+    fine.elements = O.sort_element_nodes(fine.elements)
+    # conductivity of a fine cell = that of the unit cube containing its centre
+    rng = np.random.default_rng(4)
+    sgrid = np.where(rng.random((n,) * dim + (dim,)) < 0.5, 1.0, 9.0)
+    np.testing.assert_array_equal(O.conductivity_per_element(base, sgrid, (0.0,) * dim), cond)
+    A = O.assemble_checkerboard(fine, O.conductivity_per_element(fine, sgrid, (0.0,) * dim), 0.0).tocsr()
+    b = O.assemble_vector(fine)
+    interior = O.list_interior_nodes(fine)
+    u = np.zeros(fine.nnodes())
+    u[interior] = spla.spsolve(A[interior][:, interior].tocsc(), b[interior])
+    rep = implicit.construct_full_grid(grids).reshape(-1, dim)
+    scale = 1 << 12
+    w = np.array([1, 1 << 20, 1 << 40][:dim])
+    key = lambda p: np.round(p * scale).astype(np.int64) @ w
+    tk = key(fine.nodes)
+    order = np.argsort(tk)
+    pos = np.searchsorted(tk[order], key(rep))
+    assert np.all(tk[order][pos] == key(rep))
+    want = u[order[pos]].reshape(top.x.shape, order="F")
+    assert np.abs(top.x - want).max() <= 1e-9 * np.abs(want).max()
