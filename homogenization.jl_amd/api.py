@@ -246,15 +246,26 @@ def norm_unique(r: DeviceMatrix) -> float:
     return out.value
 
 
-class L2PlusDivAGrad:
+class _Operator:
+    """The library keeps ONE operator (per-cell tensors + lambda) per grid; operator objects re-bind themselves
+    when they are used after another one (the reference passes the operator to every call instead)."""
+
+    def _bind(self):
+        g = self.implicit
+        if getattr(g, "_bound_op", None) is not self:
+            g.set_operator(self.sigmas, self._lam)
+            g._bound_op = self
+
+
+class L2PlusDivAGrad(_Operator):
     """lam*I - div(sigma grad), sigma constant per coarse cell; carries the Dirichlet constraint
-    (held by the grid).  Mutable lam like the reference's struct."""
+    (held by the grid).  Mutable lam like the reference's struct.  ref: src/build_local_operators.jl:26-32"""
 
     def __init__(self, implicit: ImplicitFineGrid, lam: float, sigmas):
         self.implicit = implicit
         self._lam = float(lam)
         self.sigmas = np.ascontiguousarray(sigmas, dtype=np.float64)
-        implicit.set_operator(self.sigmas, self._lam)
+        self._bind()
 
     @property
     def lam(self):
@@ -263,7 +274,20 @@ class L2PlusDivAGrad:
     @lam.setter
     def lam(self, v):
         self._lam = float(v)
-        self.implicit.set_lambda(self._lam)
+        if getattr(self.implicit, "_bound_op", None) is self:
+            self.implicit.set_lambda(self._lam)
+
+
+class SimpleDiffusion(_Operator):
+    """-a * Laplacian with a scalar coefficient, no mass term (src/build_local_operators.jl:14-24,
+    src/apply_local_operators.jl:40-72): the same kernels with sigma = (a, ..., a) in every cell and lambda = 0."""
+
+    def __init__(self, implicit: ImplicitFineGrid, a: float = 1.0):
+        self.implicit = implicit
+        self.a = float(a)
+        self._lam = 0.0
+        self.sigmas = np.full((implicit.base.elements.shape[0], implicit.base.dim), self.a)
+        self._bind()
 
 
 class LevelState:
@@ -281,8 +305,9 @@ class LevelState:
         return [self.x.h, self.b.h, self.r.h, self.p.h, self.Ap.h]
 
 
-def mul(alpha, implicit: ImplicitFineGrid, A: L2PlusDivAGrad, x: DeviceMatrix, y: DeviceMatrix):
-    """y <- alpha*A*x + y   (mul!(alpha, base, A, x, y))"""
+def mul(alpha, implicit: ImplicitFineGrid, A, x: DeviceMatrix, y: DeviceMatrix):
+    """y <- alpha*A*x + y   (mul!(alpha, base, A, x, y); A: L2PlusDivAGrad or SimpleDiffusion)"""
+    A._bind()
     L.check(L.load().hmg_apply(implicit.h, x.level, float(alpha), x.h, y.h))
 
 
@@ -293,6 +318,7 @@ def apply_ex(alpha, implicit: ImplicitFineGrid, x: DeviceMatrix, src, out: Devic
 
 
 def local_residual(implicit, A, curr: LevelState, k: int):
+    A._bind()
     L.check(L.load().hmg_residual(implicit.h, k, curr.x.h, curr.b.h, curr.r.h))
 
 
@@ -372,6 +398,7 @@ def integrate_area(v: DeviceMatrix, implicit: ImplicitFineGrid, nsubset: int) ->
 
 
 def smoothing_steps(steps, implicit, ops, curr: LevelState, k: int):
+    ops._bind()
     L.check(L.load().hmg_smooth(implicit.h, k, steps, curr.x.h, curr.b.h, curr.r.h, curr.p.h, curr.Ap.h))
 
 
@@ -390,6 +417,7 @@ class BaseLevel:
 def vcycle(implicit: ImplicitFineGrid, base: BaseLevel, ops, levels, k: int, steps: int = 2, steps_coarse: int = 2):
     """vcycle!(implicit, base, ops, levels, k, steps).  steps_coarse = 2 reproduces the reference,
     which does not forward `steps` to the recursive call (src/multigrid.jl:109)."""
+    ops[k - 1]._bind()
     arr = (ctypes.c_void_p * (5 * len(levels)))()
     for i, st in enumerate(levels):
         for q, h in enumerate(st.handles()):
