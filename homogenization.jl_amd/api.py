@@ -199,6 +199,12 @@ class DeviceMatrix:
         L.check(self._lib.hmg_vec_copy(self.h, src.h))
         return self
 
+    def similar(self):                       # similar(x)
+        return DeviceMatrix(self.implicit, self.level)
+
+    def copy(self):                          # copy(x)
+        return self.similar().copyto(self)
+
     def device_ptr(self):
         return int(self._lib.hmg_vec_device_ptr(self.h) or 0)
 
@@ -228,6 +234,11 @@ def dot(x: DeviceMatrix, y: DeviceMatrix) -> float:
     out = ctypes.c_double()
     L.check(L.load().hmg_vec_dot(x.h, y.h, ctypes.byref(out)))
     return out.value
+
+
+def norm(x: DeviceMatrix) -> float:
+    """norm(x) over the raw storage: shared DOFs counted once per copy, like BLAS on the reference's Matrix."""
+    return float(np.sqrt(dot(x, x)))
 
 
 def axpy(alpha, x: DeviceMatrix, y: DeviceMatrix):

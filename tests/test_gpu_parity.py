@@ -178,6 +178,11 @@ def test_blas1(case3):
     np.testing.assert_allclose(db.to_host(), b + 0.37 * a, rtol=0, atol=1e-15 * 8)
     hmg.xpby(da, -1.7, db)
     np.testing.assert_allclose(db.to_host(), a - 1.7 * (b + 0.37 * a), rtol=0, atol=1e-14)
+    assert abs(hmg.norm(da) - np.linalg.norm(a)) <= 1e-13 * np.linalg.norm(a)
+    dc = da.copy()                                                       # copy / similar / fill!
+    da.fill(0.0)
+    np.testing.assert_array_equal(dc.to_host(), a)
+    assert dc.similar().shape == a.shape and not da.to_host().any()
 
 
 @pytest.mark.parametrize("which", ["case3", "case2"])
