@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -58,7 +59,9 @@ struct DevBuf {
 struct LevelBufs {
     DevBuf<uint64_t> meta;
     DevBuf<uint16_t> lpos, sweep_slot;
-    DevBuf<int> slab_k, slab_rng;
+    DevBuf<int> slab_head;
+    DevBuf<uint32_t> slab_ld_word, slab_cp_word;
+    DevBuf<uint16_t> slab_cp_slot;
     int nslab = 0, slab_lds_nodes = 0;
     DevBuf<uint32_t> pos32, pos32w, sweep32;
     DevBuf<double> ctab;
@@ -291,9 +294,12 @@ static void upload_levels(hmg_grid *g)
                 B.sweep32.upload(s32, s);
             }
             if (T.dim == 3 && sizeof(double) * (size_t)(232 + T.lds_g0 + T.nf + T.lds_g1) > 160 * 1024) {
-                // greedy slabs of k-planes: planes [k0-1, k1] (+ guards) must fit ~150 KiB of LDS
-                const int cap = (150 * 1024) / 8 - 232;
-                const int slab_g0 = ((T.m + 2) * (T.m + 3)) / 2 + 2;
+                // greedy slabs of k-planes: the rolling window [k0-1, k1] (+ zero guard) of k_apply_slab must fit
+                // half of the CU's LDS, so that two workgroups are resident (HMG_SLAB_LDS_KB overrides, dev knob)
+                int kb = 78;
+                if (const char *e = std::getenv("HMG_SLAB_LDS_KB")) kb = std::max(16, std::min(158, std::atoi(e)));
+                const int cap = (kb * 1024) / 8 - 232;
+                const int slab_g0 = 0;
                 auto po = [&](int k) {
                     long long n1 = T.m + 1, n2 = T.m + 1 - std::min(std::max(k, 0), T.m + 1);
                     return (int)((n1 * (n1 + 1) * (n1 + 2) - n2 * (n2 + 1) * (n2 + 2)) / 6);
@@ -310,17 +316,13 @@ static void upload_levels(hmg_grid *g)
                 }
                 B.nslab = (int)sk.size() - 1;
                 B.slab_lds_nodes = maxn;
-                B.slab_k.upload(sk, s);
-                // slot ranges per slab: inside every entity segment the slots are ordered by plane k, so the
-                // slots of planes [ka, kb) are one contiguous run.  16 segments: 4 corners, 6 edges, 4 faces,
-                // interior (+1 unused).
+                // Inside every entity segment the slots are ordered by plane k, so the slots of planes [ka, kb) are
+                // one contiguous run.  15 segments: 4 corners, 6 edges, 4 faces, interior.
                 std::vector<std::pair<int, int>> seg;
                 for (int c = 0; c < T.ncorner; ++c) seg.push_back({c, c + 1});
                 for (int e = 0; e < T.nedge; ++e) seg.push_back({T.off_edge + e * T.nei, T.off_edge + (e + 1) * T.nei});
                 for (int f = 0; f < T.nface; ++f) seg.push_back({T.off_face + f * T.nfi, T.off_face + (f + 1) * T.nfi});
-                seg.push_back({T.off_int, T.nf});
-                while (seg.size() < 16) seg.push_back({0, 0});
-                if (seg.size() != 16) throw std::runtime_error("apply slabs: unexpected entity count");
+                seg.push_back({T.off_int, T.nf});                    // interior last: the kernel's fast path
                 auto run = [&](std::pair<int, int> sg, int ka, int kb) {   // slots of the segment with ka <= k < kb
                     int b = sg.second, e = sg.first;
                     for (int t = sg.first; t < sg.second; ++t) {
@@ -337,17 +339,40 @@ static void upload_levels(hmg_grid *g)
                     }
                     return std::pair<int, int>{b, e};
                 };
-                std::vector<int> rng((size_t)B.nslab * 64, 0);
-                for (int sl = 0; sl < B.nslab; ++sl)
-                    for (int r = 0; r < 16; ++r) {
-                        auto ld = run(seg[r], sk[sl] - 1, sk[sl + 1] + 1);   // planes held in LDS
-                        auto cp = run(seg[r], sk[sl], sk[sl + 1]);           // planes evaluated
-                        rng[sl * 64 + 2 * r] = ld.first;
-                        rng[sl * 64 + 2 * r + 1] = ld.second;
-                        rng[sl * 64 + 32 + 2 * r] = cp.first;
-                        rng[sl * 64 + 32 + 2 * r + 1] = cp.second;
+                // flat lists per slab (k_apply_slab): slots new in the rolling window (planes k0-1 and k0 come
+                // from the previous slab's LDS image) and slots evaluated (surface entities first)
+                std::vector<int> head((size_t)B.nslab * 8, 0);
+                std::vector<uint32_t> ldw, cpw;
+                std::vector<uint16_t> cps;
+                for (int sl = 0; sl < B.nslab; ++sl) {
+                    head[sl * 8 + 0] = sk[sl];
+                    head[sl * 8 + 1] = (int)ldw.size();
+                    head[sl * 8 + 3] = (int)cpw.size();
+                    for (size_t si = 0; si < seg.size(); ++si) {
+                        const auto &sg = seg[si];
+                        if (si + 1 == seg.size()) head[sl * 8 + 5] = (int)cpw.size() - head[sl * 8 + 3];   // surface entries
+                        auto ld = run(sg, sl == 0 ? 0 : sk[sl] + 1, sk[sl + 1] + 1);
+                        for (int t = ld.first; t < ld.second; ++t)
+                            ldw.push_back((uint32_t)(T.meta[t] & 0xffffu) | ((uint32_t)t << 16));
+                        auto cp = run(sg, sk[sl], sk[sl + 1]);
+                        for (int t = cp.first; t < cp.second; ++t) {
+                            cpw.push_back(((uint32_t)T.slot_ijk[3 * t] & 127u) | (((uint32_t)T.slot_ijk[3 * t + 1] & 127u) << 7) |
+                                          (((uint32_t)T.slot_ijk[3 * t + 2] & 127u) << 14) | ((uint32_t)T.slot_cls[t] << 21));
+                            cps.push_back((uint16_t)t);
+                        }
                     }
-                B.slab_rng.upload(rng, s);
+                    head[sl * 8 + 2] = (int)ldw.size() - head[sl * 8 + 1];
+                    head[sl * 8 + 4] = (int)cpw.size() - head[sl * 8 + 3];
+                }
+                if ((int)ldw.size() != T.nf || (int)cpw.size() != T.nf)
+                    throw std::runtime_error("apply slabs: the slab lists do not cover the cell exactly once");
+                ldw.resize(ldw.size() + TABLE_PAD, 0u);
+                cpw.resize(cpw.size() + TABLE_PAD, 0u);
+                cps.resize(cps.size() + TABLE_PAD, (uint16_t)0);
+                B.slab_head.upload(head, s);
+                B.slab_ld_word.upload(ldw, s);
+                B.slab_cp_word.upload(cpw, s);
+                B.slab_cp_slot.upload(cps, s);
             }
             {
                 std::vector<uint16_t> ss(T.sweep_slot);
@@ -423,10 +448,12 @@ void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);   // defined belo
 void set_slab(hmg_grid *g, const LevelDev &lv)
 {
     const LevelBufs &B = *g->lb[lv.level - 1];
-    g->md.slab_k = B.slab_k.p;
-    g->md.slab_rng = B.slab_rng.p;
-    g->md.nslab = B.nslab;
-    g->md.slab_lds_nodes = B.slab_lds_nodes;
+    g->md.slab.head = B.slab_head.p;
+    g->md.slab.ld_word = B.slab_ld_word.p;
+    g->md.slab.cp_word = B.slab_cp_word.p;
+    g->md.slab.cp_slot = B.slab_cp_slot.p;
+    g->md.slab.nslab = B.nslab;
+    g->md.slab.lds_nodes = B.slab_lds_nodes;
 }
 
 // every operator apply goes through here: optional HIP-event bracketing for bench.py's roofline
@@ -584,7 +611,7 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
         apply_then_sum(g, lv, a, false, -1, -1);
     }
     int cur = S_RS, other = S_RS2;
-    if (g->fuse_cg && apply_lds_bytes(lv) <= 160 * 1024) {
+    if (g->fuse_cg) {
         // p-update and both reductions ride along with the operator apply (see k_apply<.., FUSED>)
         // Per step:  fused apply  [x += alpha_prev p_old;  p = r + beta p_old;  Ap = A p;  p.Ap (, r.r)]
         //            interface sum of Ap

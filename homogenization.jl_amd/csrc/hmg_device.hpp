@@ -34,6 +34,15 @@ struct LevelDev {
     const double *dphi;            // [3*nf]
 };
 
+// Rolling-window tables of k_apply_slab (cells larger than the LDS), one set per such level.
+struct SlabTables {
+    const int *head;             // per slab 8 ints: k0, ld_off, ld_cnt, cp_off, cp_cnt, cp_surf (surface entries first), 0, 0
+    const uint32_t *ld_word;     // slots new in the window: LDS lattice position L | slot << 16   (+ TABLE_PAD)
+    const uint32_t *cp_word;     // evaluated slots: i | j<<7 | k<<14 | cls<<21 (decode32w)        (+ TABLE_PAD)
+    const uint16_t *cp_slot;     // evaluated slots: storage slot                                  (+ TABLE_PAD)
+    int nslab, lds_nodes;
+};
+
 struct MeshDev {
     int dim;
     int64_t ncells, nnodes;
@@ -53,9 +62,7 @@ struct MeshDev {
     const uint8_t *mult;         // 16 per cell: number of copies of each entity (bit order of the masks)
     double *blockpart;           // 2 per cell: scratch for the fused apply's block sums
     // slab decomposition of the finest level when one cell exceeds the LDS (set per launch by the host)
-    const int *slab_k;           // nslab + 1 plane boundaries
-    const int *slab_rng;         // per slab 2 x 16 (begin, end) slot ranges: load phase, compute phase
-    int nslab, slab_lds_nodes;
+    SlabTables slab;             // set per level before an apply of a level whose cell exceeds the LDS
 };
 
 struct ApplyArgs {

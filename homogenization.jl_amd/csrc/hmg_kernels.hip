@@ -379,72 +379,186 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     }
 }
 
-// Slab variant for cells whose lattice image exceeds the LDS (level 7 in 3D: 374 KiB): the cell is
-// processed in slabs of consecutive k-planes; the LDS holds planes [k0-1, k1] of the lattice image, nodes of
-// planes [k0, k1) are evaluated.  Storage is entity-major with lattice order (k slowest) inside every entity,
-// so the slots of a range of planes are one contiguous run per entity: slab_rng holds, per slab, NR = 16
-// (begin, end) slot ranges for the load phase followed by NR for the compute phase.  Same tables, same
-// arithmetic as k_apply; not fused.
-constexpr int SLAB_NR = 16;
-template <int DIM, int NT>
-__global__ void __launch_bounds__(NT)
-k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a,
-             const int *__restrict__ slab_k, const int *__restrict__ slab_rng, int nslab, int lds_nodes)
+// Slab variant for cells whose lattice image exceeds the LDS (level 7 in 3D: 374 KiB).  The cell is processed in
+// slabs of consecutive k-planes through a ROLLING window: the LDS holds planes [k0-1, k1] of the lattice image, the
+// nodes of planes [k0, k1) are evaluated, then planes k1-1 and k1 are moved to the front of the window (LDS -> LDS)
+// and only planes k1+1 .. k1' come from HBM -- every slot is read from HBM exactly once, so the load-phase side
+// effects of the fused CG pass (p-update, x-update, r.r) can be attached to it as in k_apply.  Per slab the host
+// provides two flat lists (SlabTables): the slots that are new in the window (LDS position | slot << 16) and the
+// slots that are evaluated (addressing word + slot; surface entities first, then the cell interior), so that both
+// phases are single batched / software-pipelined loops instead of one latency-bound loop per entity.  The window
+// is sized so that two workgroups are resident per CU (one loads while the other computes).  Same arithmetic as
+// k_apply.
+template <int DIM, int NT, bool FUSED>
+__global__ void __launch_bounds__(NT, 8)
+k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a, SlabTables st)
 {
     constexpr int NDIR = DIM == 3 ? 15 : 7;
     constexpr int NTERM = DIM == 3 ? 7 : 4;
+    constexpr int HB = FUSED ? 2 : 4;               // loads in flight per thread and stream in the load phase (64-VGPR budget)
     extern __shared__ double smem[];
     double *W = smem;
-    double *img = smem + WSZ;                       // lds_nodes doubles: [guard | planes k0-1..k1 | guard g1]
+    double *img = smem + WSZ;                       // lds_nodes doubles: [planes k0-1..k1 | zero guard]
     const int tid = threadIdx.x;
     const int64_t cell = blockIdx.x;
     const int m = lv.m;
-    const int slab_g0 = ((m + 2) * (m + 3)) / 2 + 2;   // reach of the plane-below taps of plane-0 nodes
 
-    double s[NTERM];
-    cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
-    for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
-        const double *c = lv.ctab + (size_t)idx * NTERM;
-        double w = 0.0;
+    {
+        double s[NTERM];
+        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
+        for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
+            const double *c = lv.ctab + (size_t)idx * NTERM;
+            double w = 0.0;
 #pragma unroll
-        for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
-        W[idx] = w;
+            for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
+            W[idx] = w;
+        }
     }
     const double *xc = a.x + cell * lv.ld;
+    const double *x2c = FUSED && a.x2 ? a.x2 + cell * lv.ld : nullptr;
+    double *xoc = FUSED && a.xout ? a.xout + cell * lv.ld : nullptr;
+    double *xac = FUSED && a.xacc ? a.xacc + cell * lv.ld : nullptr;
+    const double beta = to_sgpr(x2c ? a.scal[a.s_num] / a.scal[a.s_den] : 0.0);
+    const double ax = to_sgpr(xac ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0);
     const uint32_t dm = (a.flags & 1) ? dmask[cell] : 0u;
     const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
-    double *oc = a.out + cell * lv.ld;
+    double *oc = a.out ? a.out + cell * lv.ld : nullptr;
+    uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
+    if (FUSED) {
+        const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mq[q] = __builtin_amdgcn_readfirstlane(mp[q]);
+    }
+    double rr = 0.0, pap = 0.0;
     auto plane_off = [&](int k) {   // PO(k) = number of lattice nodes in planes < k
         if (k <= 0) return 0;
         if (k > m + 1) k = m + 1;
         const long long n1 = m + 1, n2 = m + 1 - k;
         return (int)((n1 * (n1 + 1) * (n1 + 2) - n2 * (n2 + 1) * (n2 + 2)) / 6);
     };
-    for (int sl = 0; sl < nslab; ++sl) {
-        const int k0 = slab_k[sl], k1 = slab_k[sl + 1];
-        const int lo = plane_off(k0 - 1), hi = plane_off(k1 + 1);   // lattice range held in LDS: [lo, hi)
-        double *xs = img + slab_g0 - lo;                            // xs[L] valid for lo - slab_g0 <= L < hi + g1
-        const int *rng = slab_rng + sl * 4 * SLAB_NR;
-        __syncthreads();                                            // previous slab fully consumed
-        // guards only: every image position in [lo, hi) is overwritten by the load below
-        for (int q = tid; q < slab_g0; q += NT) img[q] = 0.0;
-        for (int q = slab_g0 + (hi - lo) + tid; q < lds_nodes; q += NT) img[q] = 0.0;
-        for (int r = 0; r < SLAB_NR; ++r) {
-            const int b = rng[2 * r], e = rng[2 * r + 1];
-#pragma unroll 4
-            for (int t = b + tid; t < e; t += NT) xs[lv.lpos[t]] = xc[t];
-        }
-        __syncthreads();
-        for (int r = 0; r < SLAB_NR; ++r) {
-            const int b = rng[2 * SLAB_NR + 2 * r], e = rng[2 * SLAB_NR + 2 * r + 1];
-            for (int t = b + tid; t < e; t += NT) {
-                int L, len, A, B, cls, k;
-                decode32w(lv.pos32w[t], m, L, len, A, B, cls, k);
-                double ctr;
-                double o = (sc ? sc[t] : 0.0) + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
-                if (cls > 0 && ((dm >> (cls - 1)) & 1u)) o = 0.0;
-                oc[t] = o;
+    __syncthreads();                                                // W complete
+    double w0[NDIR];                                                // interior weight row, SGPR-resident
+#pragma unroll
+    for (int d = 0; d < NDIR; ++d) w0[d] = to_sgpr(W[d]);
+    int lo_prev = 0;
+    for (int sl = 0; sl < st.nslab; ++sl) {
+        const int *hd = st.head + 8 * sl;                           // k0, ld_off, ld_cnt, cp_off, cp_cnt, cp_surf
+        const int k0 = hd[0], ld_off = hd[1], ld_cnt = hd[2], cp_off = hd[3], cp_cnt = hd[4], cp_surf = hd[5];
+        const int lo = plane_off(k0 - 1);                           // lattice range held in LDS: [lo, PO(k1 + 1))
+        double *xs = img - lo;                                      // xs[L] valid inside that range (+ zero guard)
+        if (sl > 0) {
+            __syncthreads();                                        // previous slab fully consumed
+            // planes k0-1 and k0 (the last evaluated plane and the upper halo of the previous slab) move to the
+            // front of the window; destination below source, ascending chunks, one barrier between a chunk's
+            // reads and its writes
+            const int cnt = plane_off(k0 + 1) - lo, src = lo - lo_prev;
+            const int nchunk = (cnt + NT - 1) / NT;
+            for (int c = 0; c < nchunk; ++c) {
+                const int q = c * NT + tid;
+                const double v = q < cnt ? img[src + q] : 0.0;
+                __syncthreads();
+                if (q < cnt) img[q] = v;
             }
+        }
+        for (int q = (sl > 0 ? plane_off(k0 + 1) - lo : 0) + tid; q < st.lds_nodes; q += NT) img[q] = 0.0;   // stale data + guard
+        __syncthreads();
+        // planes new in the window: HBM -> LDS, every slot once; batches of HB slots per thread, all loads of a
+        // batch before its stores (xout / xacc may alias x2)
+        for (int q0 = 0; q0 < ld_cnt; q0 += HB * NT) {
+            uint32_t wd[HB];
+            double xv[HB], x2v[HB], xav[HB];
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int v = q0 + q * NT + tid;
+                wd[q] = st.ld_word[ld_off + v];                      // (list is padded: no bounds check)
+            }
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int v = q0 + q * NT + tid;
+                if (v < ld_cnt) {
+                    const int t = (int)(wd[q] >> 16);
+                    xv[q] = xc[t];
+                    x2v[q] = x2c ? x2c[t] : 0.0;
+                    xav[q] = xac ? xac[t] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                const int v = q0 + q * NT + tid;
+                if (v < ld_cnt) {
+                    const int t = (int)(wd[q] >> 16);
+                    double val = xv[q];
+                    if (FUSED) {
+                        if (xac) xac[t] = xav[q] + ax * x2v[q];
+                        if (x2c) val = val + beta * x2v[q];
+                        if (xoc) xoc[t] = val;
+                        rr += val * val;
+                    }
+                    xs[wd[q] & 0xffffu] = val;
+                }
+            }
+        }
+        // evaluated planes, surface entities first: addressing word and slot fetched two iterations ahead of use
+        const int ib = cp_off + cp_surf;                            // start of the interior part of the list
+        uint32_t p0 = st.cp_word[cp_off + tid], p1 = st.cp_word[cp_off + tid + NT];
+        int s0 = (int)st.cp_slot[cp_off + tid], s1 = (int)st.cp_slot[cp_off + tid + NT];
+        uint32_t q0 = st.cp_word[ib + tid], q1 = st.cp_word[ib + tid + NT];
+        int t0 = (int)st.cp_slot[ib + tid], t1 = (int)st.cp_slot[ib + tid + NT];
+        __syncthreads();
+        const int nit_s = (cp_surf + NT - 1) / NT;
+        for (int it = 0; it < nit_s; ++it) {
+            const int v = it * NT + tid;
+            const uint32_t pw = p0;
+            const int t = s0;
+            p0 = p1;
+            s0 = s1;
+            p1 = st.cp_word[cp_off + v + 2 * NT];
+            s1 = (int)st.cp_slot[cp_off + v + 2 * NT];
+            if (v < cp_surf) {
+                const double sv = sc ? sc[t] : 0.0;
+                int L, len, A, B, cls, k;
+                decode32w(pw, m, L, len, A, B, cls, k);
+                double ctr;
+                double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+                if ((dm >> (cls - 1)) & 1u) o = 0.0;
+                if (!FUSED || oc) oc[t] = o;
+                if (FUSED) {
+                    const int en = cls - 1;
+                    const uint32_t word = en < 4 ? mq[0] : en < 8 ? mq[1] : en < 12 ? mq[2] : mq[3];
+                    const uint32_t mu = (word >> (8 * (en & 3))) & 0xffu;
+                    pap += (double)mu * (ctr * o);
+                }
+            }
+        }
+        const int n_int = cp_cnt - cp_surf;
+        const int nit_i = (n_int + NT - 1) / NT;
+        for (int it = 0; it < nit_i; ++it) {                        // cell interior: one weight row for all nodes
+            const int v = it * NT + tid;
+            const uint32_t pw = q0;
+            const int t = t0;
+            q0 = q1;
+            t0 = t1;
+            q1 = st.cp_word[ib + v + 2 * NT];
+            t1 = (int)st.cp_slot[ib + v + 2 * NT];
+            if (v < n_int) {
+                const double sv = sc ? sc[t] : 0.0;
+                int L, len, A, B, cls, k;
+                decode32w(pw, m, L, len, A, B, cls, k);
+                double ctr;
+                const double o = sv + stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
+                if (!FUSED || oc) oc[t] = o;
+                if (FUSED) pap += ctr * o;
+            }
+        }
+        lo_prev = lo;
+    }
+    if (FUSED) {
+        __syncthreads();
+        const double s_pap = block_sum(pap, smem);
+        const double s_rr = block_sum(rr, smem);
+        if (tid == 0) {
+            a.blockpart[2 * cell] = s_pap;
+            a.blockpart[2 * cell + 1] = s_rr;
         }
     }
 }
@@ -489,14 +603,13 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
 {
     const size_t lds = apply_lds_bytes(lv);
     if (lds > 160 * 1024) {
-        if (FUSED) throw std::runtime_error("fused CG pass is not available for cells larger than the LDS");
-        if (DIM != 3 || !mesh.slab_k) throw std::runtime_error("operator apply: cell does not fit the LDS");
-        auto kern = k_apply_slab<DIM, 1024>;
-        const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab_lds_nodes);
+        if (DIM != 3 || !mesh.slab.head) throw std::runtime_error("operator apply: cell does not fit the LDS");
+        auto kern = k_apply_slab<3, 1024, FUSED>;
+        const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab.lds_nodes);
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         if (a.cell_list) throw std::runtime_error("cell lists are not supported by the slab apply");
         hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
-                           mesh.slab_k, mesh.slab_rng, mesh.nslab, mesh.slab_lds_nodes);
+                           mesh.slab);
         check_launch();
         return;
     }

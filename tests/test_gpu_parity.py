@@ -470,11 +470,17 @@ def test_driver_save_writes_vtk(ctx, tmp_path):
         assert np.isfinite(out["point_data"]["v"]).all()
 
 
-def test_level7_cells_larger_than_lds(oracle, ctx):
-    """refinements = 6: Nf = 47 905 (374 KiB per cell) does not fit the 160 KiB LDS; the slab-wise apply and the
-    unfused smoother take over.  ref: src/apply_local_operators.jl:85-133, src/multigrid.jl:46-71"""
+@pytest.mark.parametrize("fused", [1, 0])
+def test_level7_cells_larger_than_lds(oracle, ctx, fused):
+    """refinements = 6: Nf = 47 905 (374 KiB per cell) does not fit the 160 KiB LDS; the slab-wise apply (rolling
+    window of k-planes, fused CG pass included) takes over.  ref: src/apply_local_operators.jl:85-133,
+    src/multigrid.jl:46-119"""
     O = oracle
-    c = Case(O, ctx, 3, 1, 7, lam=0.9, perturb=0.1, seed=13, ordered=False)
+    ctx.set_option("fuse_cg", fused)
+    try:
+        c = Case(O, ctx, 3, 1, 7, lam=0.9, perturb=0.1, seed=13, ordered=False)
+    finally:
+        ctx.set_option("fuse_cg", 1)
     lev = 7
     x, y = c.rand(lev), c.rand(lev)
     want = y.copy(order="F")
@@ -485,10 +491,11 @@ def test_level7_cells_larger_than_lds(oracle, ctx):
     st = _oracle_state(c, lev)
     dst = hmg.LevelState(c.g, lev)
     dst.x.from_host(st.x); dst.b.from_host(st.b)
-    O.smoothing_steps(2, c.impl, c.ops[lev - 1], st, lev)
-    hmg.smoothing_steps(2, c.g, c.A, dst, lev)
+    O.smoothing_steps(3, c.impl, c.ops[lev - 1], st, lev)
+    hmg.smoothing_steps(3, c.g, c.A, dst, lev)
     assert relerr(dst.x.to_host(), st.x) <= 1e-10
     assert relerr(dst.r.to_host(), st.r) <= 1e-10
+    assert relerr(dst.p.to_host(), st.p) <= 1e-10
     # transfer to / from level 6
     P = c.impl.reference.interops[lev - 2]
     wantb = np.zeros((c.impl.nf(lev - 1), c.mesh.nelements()), order="F")
@@ -496,6 +503,17 @@ def test_level7_cells_larger_than_lds(oracle, ctx):
     db = hmg.DeviceMatrix(c.g, lev - 1)
     hmg.restrict_to(db, c.g, dst.r)
     assert relerr(db.to_host(), wantb) <= 1e-10
+    if fused:                                                            # one V-cycle through all 7 levels
+        c = Case(O, ctx, 3, 2, 7, lam=0.9, perturb=0.1, seed=14)         # (2^3 cubes: level 1 has an interior node)
+        sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(lev)]
+        sts[-1] = _oracle_state(c, lev)
+        dsts = [hmg.LevelState(c.g, i + 1) for i in range(lev)]
+        dsts[-1].x.from_host(sts[-1].x); dsts[-1].b.from_host(sts[-1].b)
+        base, dbase = O.make_base_level(c.mesh, c.sig, 0.9), hmg.BaseLevel(c.g)
+        O.vcycle(c.impl, base, c.ops, sts, lev, 3)
+        hmg.vcycle(c.g, dbase, [c.A] * lev, dsts, lev, 3)
+        assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9
+        assert relerr(dsts[-1].r.to_host(), sts[-1].r) <= 1e-8
 
 
 def test_level8_triangles_maximum_size(oracle, ctx):
