@@ -296,7 +296,7 @@ static void upload_levels(hmg_grid *g)
             if (T.dim == 3 && sizeof(double) * (size_t)(232 + T.lds_g0 + T.nf + T.lds_g1) > 160 * 1024) {
                 // greedy slabs of k-planes: the rolling window [k0-1, k1] (+ zero guard) of k_apply_slab must fit
                 // half of the CU's LDS, so that two workgroups are resident (HMG_SLAB_LDS_KB overrides, dev knob)
-                int kb = 78;
+                int kb = 70;
                 if (const char *e = std::getenv("HMG_SLAB_LDS_KB")) kb = std::max(16, std::min(158, std::atoi(e)));
                 const int cap = (kb * 1024) / 8 - 232;
                 const int slab_g0 = 0;

@@ -395,7 +395,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
 {
     constexpr int NDIR = DIM == 3 ? 15 : 7;
     constexpr int NTERM = DIM == 3 ? 7 : 4;
-    constexpr int HB = FUSED ? 2 : 4;               // loads in flight per thread and stream in the load phase (64-VGPR budget)
+    constexpr int HB = FUSED ? 3 : 4;               // loads in flight per thread and stream in the load phase (64-VGPR budget)
     extern __shared__ double smem[];
     double *W = smem;
     double *img = smem + WSZ;                       // lds_nodes doubles: [planes k0-1..k1 | zero guard]
