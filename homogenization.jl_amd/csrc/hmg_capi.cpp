@@ -59,9 +59,10 @@ struct DevBuf {
 struct LevelBufs {
     DevBuf<uint64_t> meta;
     DevBuf<uint16_t> lpos, sweep_slot;
-    DevBuf<int> slab_head;
-    DevBuf<uint32_t> slab_ld_word, slab_cp_word;
-    DevBuf<uint16_t> slab_cp_slot;
+    DevBuf<int> slab_head, slab_rs_head;
+    DevBuf<uint32_t> slab_ld_word, slab_cp_word, slab_rs_word;
+    DevBuf<uint16_t> slab_cp_slot, slab_rs_slot;
+    DevBuf<double> rtab;   // restriction weights in class-table layout (slab levels)
     int nslab = 0, slab_lds_nodes = 0;
     DevBuf<uint32_t> pos32, pos32w, sweep32;
     DevBuf<double> ctab;
@@ -373,6 +374,49 @@ static void upload_levels(hmg_grid *g)
                 B.slab_ld_word.upload(ldw, s);
                 B.slab_cp_word.upload(cpw, s);
                 B.slab_cp_slot.upload(cps, s);
+                if (l > 0) {
+                    // restriction through the same window (launch_restrict_slab): evaluated nodes = the even
+                    // lattice nodes (= nodes of the coarser level), output slot = their COARSE storage slot;
+                    // weights 1 / 0.5 on the taps that exist (nonzero mass entry of the class table)
+                    const LevelTables &C = g->lt[l - 1];
+                    const int mc = C.m;
+                    std::vector<int32_t> cslot((size_t)(mc + 1) * (mc + 1) * (mc + 1), -1);
+                    auto cidx = [&](int i, int j, int k) { return ((size_t)k * (mc + 1) + j) * (mc + 1) + i; };
+                    for (int q = 0; q < C.nf; ++q) cslot[cidx(C.slot_ijk[3 * q], C.slot_ijk[3 * q + 1], C.slot_ijk[3 * q + 2])] = q;
+                    std::vector<int> rhead(head);
+                    std::vector<uint32_t> rsw;
+                    std::vector<uint16_t> rss;
+                    for (int sl = 0; sl < B.nslab; ++sl) {
+                        rhead[sl * 8 + 3] = (int)rsw.size();
+                        for (size_t si = 0; si < seg.size(); ++si) {
+                            if (si + 1 == seg.size()) rhead[sl * 8 + 5] = (int)rsw.size() - rhead[sl * 8 + 3];
+                            auto cp = run(seg[si], sk[sl], sk[sl + 1]);
+                            for (int t = cp.first; t < cp.second; ++t) {
+                                const int i = T.slot_ijk[3 * t], j = T.slot_ijk[3 * t + 1], k = T.slot_ijk[3 * t + 2];
+                                if ((i | j | k) & 1) continue;
+                                const int cs = cslot[cidx(i / 2, j / 2, k / 2)];
+                                if (cs < 0) throw std::runtime_error("slab restriction: even node without a coarse slot");
+                                rsw.push_back(((uint32_t)i & 127u) | (((uint32_t)j & 127u) << 7) | (((uint32_t)k & 127u) << 14) |
+                                              ((uint32_t)T.slot_cls[t] << 21));
+                                rss.push_back((uint16_t)cs);
+                            }
+                        }
+                        rhead[sl * 8 + 4] = (int)rsw.size() - rhead[sl * 8 + 3];
+                    }
+                    if ((int)rsw.size() != C.nf) throw std::runtime_error("slab restriction: lists do not cover the coarse cell");
+                    rsw.resize(rsw.size() + TABLE_PAD, 0u);
+                    rss.resize(rss.size() + TABLE_PAD, (uint16_t)0);
+                    std::vector<double> rt(T.ctab.size(), 0.0);
+                    for (int c = 0; c < T.ncls; ++c)
+                        for (int d = 0; d < T.ndir; ++d) {
+                            const size_t e = ((size_t)c * T.ndir + d) * T.nterm + T.nterm - 1;
+                            rt[e] = T.ctab[e] != 0.0 ? (d == 0 ? 1.0 : 0.5) : 0.0;
+                        }
+                    B.slab_rs_head.upload(rhead, s);
+                    B.slab_rs_word.upload(rsw, s);
+                    B.slab_rs_slot.upload(rss, s);
+                    B.rtab.upload(rt, s);
+                }
             }
             {
                 std::vector<uint16_t> ss(T.sweep_slot);
@@ -479,6 +523,27 @@ void apply(hmg_grid *g, const LevelDev &lv, double alpha, const double *x, const
         t.launches += 1;
         t.bytes += 8.0 * (double)lv.nf * (double)g->md.ncells * (src ? 3.0 : 2.0);
     }
+}
+
+void restrict_level(hmg_grid *g, int level_fine, const double *rf, double *bc)
+{
+    // ref: src/interpolation.jl:52-62
+    const LevelDev &fine = lev(g, level_fine), &coarse = lev(g, level_fine - 1);
+    const LevelBufs &B = *g->lb[level_fine - 1];
+    if (apply_lds_bytes(fine) > 160 * 1024 && B.slab_rs_head.p) {
+        LevelDev fr = fine;
+        fr.ctab = B.rtab.p;
+        SlabTables st{};
+        st.head = B.slab_rs_head.p;
+        st.ld_word = B.slab_ld_word.p;
+        st.cp_word = B.slab_rs_word.p;
+        st.cp_slot = B.slab_rs_slot.p;
+        st.nslab = B.nslab;
+        st.lds_nodes = B.slab_lds_nodes;
+        launch_restrict_slab(g->ctx->L, fr, g->md, st, coarse.ld, rf, bc);
+        return;
+    }
+    launch_restrict(g->ctx->L, fine, coarse, g->md.ncells, rf, bc);
 }
 
 void interface_sum(hmg_grid *g, const LevelDev &lv, double *x)
@@ -775,7 +840,7 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     const Launch &L = g->ctx->L;
     smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false);
     apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                            // local residual
-    launch_restrict(L, lev(g, k), lev(g, k - 1), g->md.ncells, cur[2]->d, nxt[1]->d);
+    restrict_level(g, k, cur[2]->d, nxt[1]->d);
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st);
     launch_prolong_add(L, lev(g, k), lev(g, k - 1), g->md.ncells, nxt[0]->d, cur[0]->d);
@@ -1441,7 +1506,7 @@ int hmg_restrict(hmg_grid *g, int level_fine, hmg_vec *r_fine, hmg_vec *b_coarse
     need(g && level_fine >= 2, "restriction needs level_fine >= 2");
     check_vec(g, level_fine, r_fine, "r_fine");
     check_vec(g, level_fine - 1, b_coarse, "b_coarse");
-    launch_restrict(g->ctx->L, lev(g, level_fine), lev(g, level_fine - 1), g->md.ncells, r_fine->d, b_coarse->d);
+    restrict_level(g, level_fine, r_fine->d, b_coarse->d);
     HMG_END
 }
 

@@ -78,7 +78,9 @@ struct ApplyArgs {
     int s_num, s_den;
     double *blockpart;
     const uint8_t *mult;
-    int flags;             // bit 0: Dirichlet constraint on out; bit 1: mass term only
+    int flags;             // bit 0: Dirichlet constraint on out; bit 1: mass term only; bit 2 (slab kernel): weights =
+                           // last term of the class table, no per-cell scaling (restriction)
+    int64_t out_ld;        // column stride of out if it differs from the level's (slab restriction), else 0
     const int32_t *cell_list;   // optional: workgroup b works on cell cell_list[b] (ncell_list of them)
     int64_t ncell_list;
 };
@@ -116,6 +118,8 @@ void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh,
 // which: 0 everything; 1 only the cut edge / node groups; 2 everything else (faces, non-cut groups)
 void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which = 0);
 void launch_mask(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which /*0 dmask,1 dupmask*/);
+void launch_restrict_slab(const Launch &L, const LevelDev &fine_rtab, const MeshDev &mesh, const SlabTables &st, int ldc,
+                          const double *rf, double *bc);
 void launch_restrict(const Launch &L, const LevelDev &fine, const LevelDev &coarse, int64_t ncells,
                      const double *rf, double *bc);
 void launch_prolong_add(const Launch &L, const LevelDev &fine, const LevelDev &coarse, int64_t ncells,

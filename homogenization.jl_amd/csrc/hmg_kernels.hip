@@ -403,7 +403,9 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     const int64_t cell = blockIdx.x;
     const int m = lv.m;
 
-    {
+    if (a.flags & 4) {   // cell-independent stencil (restriction): the weight is the last term of the class table
+        for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) W[idx] = lv.ctab[(size_t)idx * NTERM + NTERM - 1];
+    } else {
         double s[NTERM];
         cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
         for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
@@ -422,7 +424,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     const double ax = to_sgpr(xac ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0);
     const uint32_t dm = (a.flags & 1) ? dmask[cell] : 0u;
     const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
-    double *oc = a.out ? a.out + cell * lv.ld : nullptr;
+    double *oc = a.out ? a.out + cell * (a.out_ld ? a.out_ld : (int64_t)lv.ld) : nullptr;
     uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
     if (FUSED) {
         const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
@@ -876,6 +878,26 @@ void launch_prolong_add(const Launch &L, const LevelDev &fine, const LevelDev &c
             HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k, dim3((unsigned)ncells), dim3(256), lds, L.stream, fine, coarse.nf, coarse.ld, xc, xf);
     }
+    check_launch();
+}
+
+// Restriction of a level whose cell exceeds the LDS: b_coarse[c] = r[c] + 0.5 * sum of r over the fine lattice
+// neighbours of c that exist in the cell -- a cell-independent 15-point stencil evaluated at the even fine nodes,
+// run through k_apply_slab's rolling window (fine.ctab -> restriction weights, st -> lists of the even nodes with
+// their COARSE storage slots).
+void launch_restrict_slab(const Launch &L, const LevelDev &fine_rtab, const MeshDev &mesh, const SlabTables &st,
+                          int ldc, const double *rf, double *bc)
+{
+    ApplyArgs a{};
+    a.alpha = 1.0;
+    a.x = rf;
+    a.out = bc;
+    a.out_ld = ldc;
+    a.flags = 4;
+    auto kern = k_apply_slab<3, 1024, false>;
+    const size_t bytes = sizeof(double) * (size_t)(WSZ + st.lds_nodes);
+    HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(1024), bytes, L.stream, fine_rtab, mesh.coef, mesh.dmask, a, st);
     check_launch();
 }
 
