@@ -607,8 +607,7 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
                            (a.xacc ? 2.0 : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
     const int64_t ncut = g->exchange || g->ex_begin ? cut_doubles(g, lv) : 0;
-    const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 &&
-                         apply_lds_bytes(lv) <= 160 * 1024 && g->md.ncells_cut > 0;
+    const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 && g->md.ncells_cut > 0;
     auto launch = [&](const int32_t *list, int64_t n) {
         ApplyArgs b = a;
         b.cell_list = list;

@@ -400,7 +400,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     double *W = smem;
     double *img = smem + WSZ;                       // lds_nodes doubles: [planes k0-1..k1 | zero guard]
     const int tid = threadIdx.x;
-    const int64_t cell = blockIdx.x;
+    const int64_t cell = a.cell_list ? (int64_t)a.cell_list[blockIdx.x] : (int64_t)blockIdx.x;
     const int m = lv.m;
 
     if (a.flags & 4) {   // cell-independent stencil (restriction): the weight is the last term of the class table
@@ -609,8 +609,9 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         auto kern = k_apply_slab<3, 1024, FUSED>;
         const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab.lds_nodes);
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        if (a.cell_list) throw std::runtime_error("cell lists are not supported by the slab apply");
-        hipLaunchKernelGGL(kern, dim3((unsigned)mesh.ncells), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
+        const int64_t nblocks = a.cell_list ? a.ncell_list : mesh.ncells;
+        if (nblocks == 0) return;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
                            mesh.slab);
         check_launch();
         return;
