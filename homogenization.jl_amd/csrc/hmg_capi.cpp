@@ -92,6 +92,7 @@ struct ApplyTimer {
 struct hmg_ctx {
     ApplyTimer timer;
     bool fuse_cg_default = true;
+    bool fold_x = true;   // V-cycle: pre-smoother's last x-update rides with the local residual
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -597,7 +598,8 @@ struct TimedRegion {   // HIP-event bracket of the finest-level operator applies
 // On a partitioned grid the cells that own a copy of a cut entity go first; their cut DOFs are packed and
 // the sum over ranks is started, then the remaining cells and interface entities are processed while it
 // is in flight.
-void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, int slot_pap, int slot_rr)
+void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, int slot_pap, int slot_rr,
+                    bool sum_out = true)
 {
     hmg_ctx *c = g->ctx;
     const Launch &L = c->L;
@@ -630,6 +632,11 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
         sums();
         return;
     }
+    if (!sum_out) {                  // cell-local result wanted (local residual before the restriction): no reductions
+        launch(nullptr, 0);
+        tr.stop();
+        return;
+    }
     if (!overlap) {
         launch(nullptr, 0);
         tr.stop();
@@ -657,8 +664,11 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
 // control returns to the caller, so of step `steps-1` only alpha = rs / p.Ap and x += alpha p are live -- the
 // interface sum of Ap, r -= alpha Ap, r.r and the last p-update (src/multigrid.jl:60-68) are skipped, and the fused
 // kernel does not even store Ap (p.Ap comes from the cell-local products and the multiplicities).
-void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
-            bool live_tail = true)
+// defer_x (with live_tail = false, fused path): the last x += alpha p is left to the caller, which folds it into
+// its next operator apply (vcycle: the local residual); returns the scalar slot of rs (alpha = scal[slot] /
+// scal[S_PAP]), or -1 if x is already up to date.
+int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
+           bool live_tail = true, bool defer_x = false)
 {
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
@@ -701,8 +711,9 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
             //  behind them on the same stream)
             apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1);
             if (dead) {
+                if (defer_x) return cur;
                 launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);   // x += (rs / p.Ap) p
-                return;
+                return -1;
             }
             launch_cg_rupdate(L, r->d, Ap->d, n, cur, S_PAP, other);      // alpha = rs / p.Ap
             scalar_sum(g, other, 1);
@@ -716,7 +727,7 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
             launch_copy_dot(L, p->d, r->d, n, cur);
             scalar_sum(g, cur, 1);
         }
-        return;
+        return -1;
     }
     launch_copy_dot(L, p->d, r->d, n, cur);                              // p = r; rs = r.r
     scalar_sum(g, cur, 1);
@@ -727,13 +738,14 @@ void smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *
         scalar_sum(g, S_PAP, 1);
         if (!live_tail && i == steps - 1) {
             launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);       // x += (rs / p.Ap) p
-            return;
+            return -1;
         }
         launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs/pAp
         scalar_sum(g, other, 1);
         launch_cg_pupdate(L, p->d, r->d, n, other, cur);                       // beta = rs'/rs
         std::swap(cur, other);
     }
+    return -1;
 }
 
 void coarse_setup(hmg_grid *g)
@@ -837,8 +849,25 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     }
     hmg_vec **nxt = st + 5 * (k - 2);
     const Launch &L = g->ctx->L;
-    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false);
-    apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                            // local residual
+    const int rs_slot = smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false, /*defer_x=*/g->ctx->fold_x);
+    if (rs_slot >= 0) {
+        // local residual with the pre-smoother's last x-update folded into its load phase:
+        // x += alpha p (written back), r = b - A x; 40 B/DOF instead of 24 + 24
+        ApplyArgs a{};
+        a.alpha = -1.0;
+        a.lambda = g->lambda;
+        a.x = cur[0]->d;
+        a.x2 = cur[3]->d;
+        a.xout = cur[0]->d;
+        a.s_num = rs_slot;
+        a.s_den = S_PAP;
+        a.src = cur[1]->d;
+        a.out = cur[2]->d;
+        a.flags = 1;
+        apply_then_sum(g, lev(g, k), a, true, -1, -1, /*sum_out=*/false);
+    } else {
+        apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                        // local residual
+    }
     restrict_level(g, k, cur[2]->d, nxt[1]->d);
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st);
@@ -975,6 +1004,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->coarse_check = std::max<int>(1, (int)value);
     else if (n == "fuse_cg")
         ctx->fuse_cg_default = value != 0;
+    else if (n == "fold_x")
+        ctx->fold_x = value != 0;
     else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
         ctx->timer.on = value > 0;
         ctx->timer.min_level = (int)value;
