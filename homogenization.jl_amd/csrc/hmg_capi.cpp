@@ -295,7 +295,9 @@ static void upload_levels(hmg_grid *g)
                 B.pos32w.upload(p32w, s);
                 B.sweep32.upload(s32, s);
             }
-            if (T.dim == 3 && sizeof(double) * (size_t)(232 + T.lds_g0 + T.nf + T.lds_g1) > 160 * 1024) {
+            // slab tables: needed by the apply of levels whose cell exceeds the LDS (level 7), and used by the
+            // restriction of every large 3D level (level 6: the whole cell is one slab)
+            if (T.dim == 3 && T.nf > 2048) {
                 // greedy slabs of k-planes: the rolling window [k0-1, k1] (+ zero guard) of k_apply_slab must fit
                 // half of the CU's LDS, so that two workgroups are resident (HMG_SLAB_LDS_KB overrides, dev knob)
                 int kb = 70;
@@ -531,7 +533,7 @@ void restrict_level(hmg_grid *g, int level_fine, const double *rf, double *bc)
     // ref: src/interpolation.jl:52-62
     const LevelDev &fine = lev(g, level_fine), &coarse = lev(g, level_fine - 1);
     const LevelBufs &B = *g->lb[level_fine - 1];
-    if (apply_lds_bytes(fine) > 160 * 1024 && B.slab_rs_head.p) {
+    if (B.slab_rs_head.p) {
         LevelDev fr = fine;
         fr.ctab = B.rtab.p;
         SlabTables st{};
