@@ -93,6 +93,7 @@ struct hmg_ctx {
     ApplyTimer timer;
     bool fuse_cg_default = true;
     bool fold_x = true;   // V-cycle: pre-smoother's last x-update rides with the local residual
+    bool swap_rp = true;  // V-cycle: step 0 of a smoother takes r itself as p (pointer exchange), see smooth()
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -669,8 +670,12 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
 // defer_x (with live_tail = false, fused path): the last x += alpha p is left to the caller, which folds it into
 // its next operator apply (vcycle: the local residual); returns the scalar slot of rs (alpha = scal[slot] /
 // scal[S_PAP]), or -1 if x is already up to date.
+// swap_rp (fused path): step 0 does not copy r into p.  p_0 = r_0 stays where it is, r_1 = r_0 - alpha Ap is written
+// into the other buffer and the device pointers of the two handles are exchanged (8 B/DOF less at step 0).  Only
+// for callers that smooth a level an even number of times before anybody looks at the handles' memory (vcycle: pre-
+// and post-smoother), so that wrapped external buffers end up holding what their names say.
 int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
-           bool live_tail = true, bool defer_x = false)
+           bool live_tail = true, bool defer_x = false, bool swap_rp = false)
 {
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
@@ -701,7 +706,7 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
             a.lambda = g->lambda;
             a.x = r->d;
             a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
-            a.xout = p->d;
+            a.xout = i == 0 && swap_rp ? nullptr : p->d;                  // (swap_rp: r_0 itself becomes p_0)
             a.xacc = i == 0 ? nullptr : x->d;                             // x += alpha_{i-1} p_{i-1}
             a.a_num = other;                                              // rs_{i-1} (after the swap below)
             a.a_den = S_PAP;                                              // p_{i-1}.Ap_{i-1}: still the old value here
@@ -712,12 +717,19 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
             // (the kernels above read the previous p.Ap from S_PAP; the reduction that overwrites it is enqueued
             //  behind them on the same stream)
             apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1);
+            const double *r_in = r->d;
+            if (i == 0 && swap_rp) {
+                std::swap(r->d, p->d);                                    // p now names r_0, r the spare buffer
+                std::swap(r->own, p->own);
+                std::swap(r->alloc_cells, p->alloc_cells);
+                r_in = p->d;
+            }
             if (dead) {
                 if (defer_x) return cur;
                 launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);   // x += (rs / p.Ap) p
                 return -1;
             }
-            launch_cg_rupdate(L, r->d, Ap->d, n, cur, S_PAP, other);      // alpha = rs / p.Ap
+            launch_cg_rupdate(L, r_in, r->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs / p.Ap
             scalar_sum(g, other, 1);
             std::swap(cur, other);
         }
@@ -851,7 +863,10 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     }
     hmg_vec **nxt = st + 5 * (k - 2);
     const Launch &L = g->ctx->L;
-    const int rs_slot = smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false, /*defer_x=*/g->ctx->fold_x);
+    // (an odd number of pointer exchanges would leave r and p swapped: both smoother calls take the same `steps`)
+    const bool swap_rp = g->ctx->swap_rp && g->fuse_cg && steps > 0;
+    const int rs_slot = smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false,
+                               /*defer_x=*/g->ctx->fold_x, swap_rp);
     if (rs_slot >= 0) {
         // local residual with the pre-smoother's last x-update folded into its load phase:
         // x += alpha p (written back), r = b - A x; 40 B/DOF instead of 24 + 24
@@ -874,7 +889,7 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st);
     launch_prolong_add(L, lev(g, k), lev(g, k - 1), g->md.ncells, nxt[0]->d, cur[0]->d);
-    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4]);
+    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], true, false, swap_rp);
 }
 
 // ---- multi-GPU cut exchange -------------------------------------------------------------------
@@ -1008,6 +1023,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->fuse_cg_default = value != 0;
     else if (n == "fold_x")
         ctx->fold_x = value != 0;
+    else if (n == "swap_rp")
+        ctx->swap_rp = value != 0;
     else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
         ctx->timer.on = value > 0;
         ctx->timer.min_level = (int)value;

@@ -139,7 +139,8 @@ void launch_copy_dot(const Launch &L, double *p, const double *r, int64_t n, int
 void launch_cg_update(const Launch &L, double *x, double *r, const double *p, const double *q, int64_t n,
                       int s_num, int s_den, int s_out);
 // alpha = scal[s_num]/scal[s_den]; r -= alpha q; scal[s_out] = r.r
-void launch_cg_rupdate(const Launch &L, double *r, const double *q, int64_t n, int s_num, int s_den, int s_out);
+void launch_cg_rupdate(const Launch &L, const double *r, double *rout, const double *q, int64_t n, int s_num, int s_den,
+                       int s_out);
 // x += (scal[a_num]/scal[a_den]) p; with_p: p = r + (scal[s_num]/scal[s_den]) p
 void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
                          int s_num, int s_den, int with_p);

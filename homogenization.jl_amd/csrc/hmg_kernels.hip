@@ -1063,29 +1063,31 @@ k_cg_update(double *x, double *r, const double *__restrict__ p, const double *__
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-// r -= alpha q, partial r.r   (alpha = scal[s_num] / scal[s_den]); the x-update rides with the next fused apply
+// rout = r - alpha q, partial rout.rout   (alpha = scal[s_num] / scal[s_den]; rout may be r); the x-update rides with
+// the next fused apply
 __global__ void __launch_bounds__(256)
-k_cg_rupdate(double *r, const double *__restrict__ q, int64_t n, const double *__restrict__ scal, int s_num, int s_den,
-             double *partials)
+k_cg_rupdate(const double *r, double *rout, const double *__restrict__ q, int64_t n, const double *__restrict__ scal,
+             int s_num, int s_den, double *partials)
 {
     __shared__ double red[4];
     const double alpha = scal[s_num] / scal[s_den];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t n2 = n >> 1;
-    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    double2 *o2 = reinterpret_cast<double2 *>(rout);
     const double2 *q2 = reinterpret_cast<const double2 *>(q);
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
         double2 rv = r2[i], qv = q2[i];
         rv.x += (-alpha) * qv.x;
         rv.y += (-alpha) * qv.y;
-        r2[i] = rv;
+        o2[i] = rv;
         acc += rv.x * rv.x;
         acc += rv.y * rv.y;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double rv = r[n - 1] + (-alpha) * q[n - 1];
-        r[n - 1] = rv;
+        rout[n - 1] = rv;
         acc += rv * rv;
     }
     double s = block_sum(acc, red);
@@ -1187,10 +1189,11 @@ void launch_cg_update(const Launch &L, double *x, double *r, const double *p, co
     check_launch();
     finalize(L, nb, s_out);
 }
-void launch_cg_rupdate(const Launch &L, double *r, const double *q, int64_t n, int s_num, int s_den, int s_out)
+void launch_cg_rupdate(const Launch &L, const double *r, double *rout, const double *q, int64_t n, int s_num, int s_den,
+                       int s_out)
 {
     int nb = stream_blocks(L, n, 8);
-    hipLaunchKernelGGL(k_cg_rupdate, dim3(nb), dim3(256), 0, L.stream, r, q, n, L.scal, s_num, s_den, L.partials);
+    hipLaunchKernelGGL(k_cg_rupdate, dim3(nb), dim3(256), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den, L.partials);
     check_launch();
     finalize(L, nb, s_out);
 }

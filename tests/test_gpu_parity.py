@@ -596,3 +596,47 @@ def test_wrapped_torch_memory(case3):
     # the library wrote into the tensor's storage: raw-storage sums agree
     assert abs(float((ty * ty).sum().item()) - hmg.dot(dy, dy)) <= 1e-9 * hmg.dot(dy, dy)
     assert dx.device_ptr() == tx.data_ptr()
+
+
+def test_vcycle_leaves_wrapped_buffers_consistent(oracle, ctx):
+    """Inside a V-cycle the smoother exchanges the device pointers of r and p at CG step 0 (no copy of r into p);
+    pre- and post-smoother make it an even number of exchanges, so caller-owned buffers wrapped as r and p must
+    hold r and p afterwards, and the result must equal the plain path (swap_rp = 0, fold_x = 0) bit for bit
+    where the arithmetic is the same (r, p) and to rounding in x."""
+    import torch
+    O = oracle
+    levels = 4
+    c = Case(O, ctx, 3, 3, levels, lam=1.0, seed=31)
+    n = c.g.ld(levels) * c.g.ncells()
+    tr = torch.zeros(n, dtype=torch.float64, device="cuda")
+    tp = torch.zeros(n, dtype=torch.float64, device="cuda")
+    st0 = _oracle_state(c, levels)
+    results = []
+    for opts in ((1, 1), (0, 0)):
+        ctx.set_option("swap_rp", opts[0]); ctx.set_option("fold_x", opts[1])
+        try:
+            dsts = [hmg.LevelState(c.g, i + 1) for i in range(levels)]
+            top = dsts[-1]
+            top.r = hmg.DeviceMatrix(c.g, levels, device_ptr=tr.data_ptr())
+            top.p = hmg.DeviceMatrix(c.g, levels, device_ptr=tp.data_ptr())
+            top.x.from_host(st0.x); top.b.from_host(st0.b)
+            hmg.vcycle(c.g, hmg.BaseLevel(c.g), [c.A] * levels, dsts, levels, 3)
+            ctx.sync()
+            assert top.r.device_ptr() == tr.data_ptr() and top.p.device_ptr() == tp.data_ptr()
+            r_host, p_host = top.r.to_host(), top.p.to_host()
+            # (the raw buffers are in storage order, to_host() in the reference's hierarchical order: per column
+            #  the same values, permuted)
+            raw_r = tr.cpu().numpy().reshape(r_host.shape, order="F")
+            raw_p = tp.cpu().numpy().reshape(p_host.shape, order="F")
+            np.testing.assert_array_equal(np.sort(raw_r, axis=0), np.sort(r_host, axis=0))
+            np.testing.assert_array_equal(np.sort(raw_p, axis=0), np.sort(p_host, axis=0))
+            assert not np.array_equal(np.sort(raw_r, axis=0), np.sort(raw_p, axis=0))
+            results.append((top.x.to_host(), r_host, p_host))
+        finally:
+            ctx.set_option("swap_rp", 1); ctx.set_option("fold_x", 1)
+    (xa, ra, pa), (xb, rb, pb) = results
+    assert relerr(xa, xb) <= 1e-13 and relerr(ra, rb) <= 1e-12 and relerr(pa, pb) <= 1e-12
+    sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(levels)]
+    sts[-1] = st0
+    O.vcycle(c.impl, O.make_base_level(c.mesh, c.sig, 1.0), c.ops, sts, levels, 3)
+    assert relerr(xa, sts[-1].x) <= 1e-9 and relerr(pa, sts[-1].p) <= 1e-8 and relerr(ra, sts[-1].r) <= 1e-8
