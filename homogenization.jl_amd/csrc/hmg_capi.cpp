@@ -808,13 +808,16 @@ void coarse_pcg(hmg_grid *g)
     if (!(bb > 0.0)) return;   // b == 0 -> x == 0
     const double tol2 = c->coarse_rtol * c->coarse_rtol * bb;
     int it = 0;
+    int slot_old = S_C0, slot_new = S_C3;          // r.z of the current / next iteration
     while (it < c->coarse_maxit) {
         int chunk = std::min(c->coarse_check, c->coarse_maxit - it);
         for (int q = 0; q < chunk; ++q) {
             launch_coarse_spmv_dot(L, A, g->c_p.p, g->c_q.p);
-            launch_coarse_update(L, A, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p, g->c_q.p);
-            launch_coarse_pupdate(L, A, g->c_p.p, g->c_z.p);
+            launch_coarse_update(L, A, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p, g->c_q.p, slot_old);
+            launch_coarse_pupdate(L, A, g->c_p.p, g->c_z.p, slot_old, slot_new);
+            std::swap(slot_old, slot_new);
         }
+        launch_coarse_residual_norm(L, A);
         it += chunk;
         HIPCHK(hipMemcpyAsync(h, c->L.scal, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));

@@ -165,10 +165,14 @@ void launch_coarse_gather_rhs(const Launch &L, const CoarseDev &A, const double 
 void launch_coarse_scatter_sol(const Launch &L, const CoarseDev &A, int64_t nnodes, const double *x, double *u);
 void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z,
                         double *p);   // x=0,r=b,z=r/d,p=z, scal[S_C0]=r.z, scal[S_C2]=b.b
-void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q);  // S_C1 = p.q
+// one iteration = these three launches; r.z lives in scal[slot_old] -> scal[slot_new] (S_C0 / S_C3, exchanged by the
+// caller every iteration), the other dot products stay in block partials that the consumer kernel sums itself
+void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q);   // partials of p.q
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
-                          const double *q);   // alpha=C0/C1; S_C3 = r.z (new); S_TMP = r.r
-void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z);   // beta=C3/C0; C0=C3
+                          const double *q, int slot_old);   // alpha = rz/p.q; partials of r.z (new), r.r
+void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z, int slot_old,
+                           int slot_new);                   // beta = rz_new/rz_old; scal[slot_new] = rz_new
+void launch_coarse_residual_norm(const Launch &L, const CoarseDev &A);   // scal[S_TMP] = r.r of the last update
 
 // b[slot, cell] = dot(dphi[slot], pvec[cell])   (rhs_a xi grad v)
 void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const double *pvec, double *b);

@@ -56,6 +56,18 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return s;
 }
 
+// Sum of nb block partials, computed redundantly (same order, same value) by every block that needs the scalar:
+// saves the separate finalize launch in launch-bound loops.  All threads call; result valid in all threads.
+__device__ __forceinline__ double sum_partials_all(const double *__restrict__ part, int nb, double *red, double *bc)
+{
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) a += part[i];
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0) *bc = s;
+    __syncthreads();
+    return *bc;
+}
+
 __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ partials, int n, double *scal, int slot)
 {
     __shared__ double red[4];
@@ -1420,13 +1432,20 @@ k_coarse_spmv_dot(CoarseDev A, const double *__restrict__ p, double *q, double *
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// One PCG iteration = 3 launches: spmv_dot (partials of p.Ap -> P0), update (sums P0 itself; partials of r.z -> P1,
+// r.r -> P2), pupdate (sums P1 itself, stores the new r.z in the other of two scalar slots).  rz lives in
+// scal[slot_old] / scal[slot_new], exchanged by the host every iteration, so no kernel overwrites a scalar that
+// another block of the same launch may still read.
 __global__ void __launch_bounds__(256)
 k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__restrict__ p, const double *__restrict__ q,
-                const double *__restrict__ scal, double *part0, double *part1)
+                const double *__restrict__ scal, int slot_old, const double *__restrict__ part_pap, int nb, double *part_rz,
+                double *part_rr)
 {
     __shared__ double red[4];
+    __shared__ double bc;
+    const double pap = sum_partials_all(part_pap, nb, red, &bc);
     // exact convergence (r = 0, e.g. a 1-unknown system after one step) makes p.Ap = 0: stay at the solution
-    const double alpha = scal[S_C1] != 0.0 ? scal[S_C0] / scal[S_C1] : 0.0;
+    const double alpha = pap != 0.0 ? scal[slot_old] / pap : 0.0;
     double rz = 0.0, rr = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
         x[i] += alpha * p[i];
@@ -1440,22 +1459,25 @@ k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__re
     double s0 = block_sum(rz, red);
     double s1 = block_sum(rr, red);
     if (threadIdx.x == 0) {
-        part0[blockIdx.x] = s0;
-        part1[blockIdx.x] = s1;
+        part_rz[blockIdx.x] = s0;
+        part_rr[blockIdx.x] = s1;
     }
 }
 
-// beta = C3/C0; p = z + beta p.  The last block to finish also rolls C0 <- C3 ... done on a
-// separate tiny launch instead (k_roll) to keep every read of C0 ahead of its overwrite.
+// beta = rz_new / rz_old; p = z + beta p; block 0 publishes rz_new in scal[slot_new]
 __global__ void __launch_bounds__(256)
-k_coarse_pupdate(CoarseDev A, double *p, const double *__restrict__ z, const double *__restrict__ scal)
+k_coarse_pupdate(CoarseDev A, double *p, const double *__restrict__ z, double *scal, int slot_old, int slot_new,
+                 const double *__restrict__ part_rz, int nb)
 {
-    const double beta = scal[S_C0] != 0.0 ? scal[S_C3] / scal[S_C0] : 0.0;
+    __shared__ double red[4];
+    __shared__ double bc;
+    const double rz_new = sum_partials_all(part_rz, nb, red, &bc);
+    const double rz_old = scal[slot_old];
+    const double beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = z[i] + beta * p[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot_new] = rz_new;
 }
-
-__global__ void k_roll(double *scal, int dst, int src) { scal[dst] = scal[src]; }
 
 static inline int coarse_blocks(const Launch &L, int64_t n)
 {
@@ -1487,29 +1509,33 @@ void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, do
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, nb, L.scal, (int)S_C2);
     check_launch();
 }
+// partial buffers of the PCG inside L.partials (>= 4096 doubles, nb <= 1024): P0 p.Ap, P1 r.z, P2 r.r
 void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q)
 {
     int nb = coarse_blocks(L, A.n);
     hipLaunchKernelGGL(k_coarse_spmv_dot, dim3(nb), dim3(256), 0, L.stream, A, p, q, L.partials);
     check_launch();
-    finalize(L, nb, S_C1);
 }
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
-                          const double *q)
+                          const double *q, int slot_old)
 {
     int nb = coarse_blocks(L, A.n);
-    hipLaunchKernelGGL(k_coarse_update, dim3(nb), dim3(256), 0, L.stream, A, x, r, z, p, q, L.scal, L.partials,
-                       L.partials + 2048);
-    check_launch();
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, nb, L.scal, (int)S_C3);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, nb, L.scal, (int)S_TMP);
+    hipLaunchKernelGGL(k_coarse_update, dim3(nb), dim3(256), 0, L.stream, A, x, r, z, p, q, L.scal, slot_old, L.partials, nb,
+                       L.partials + 1024, L.partials + 2048);
     check_launch();
 }
-void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z)
+void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z, int slot_old, int slot_new)
 {
-    hipLaunchKernelGGL(k_coarse_pupdate, dim3(coarse_blocks(L, A.n)), dim3(256), 0, L.stream, A, p, z, L.scal);
+    int nb = coarse_blocks(L, A.n);
+    hipLaunchKernelGGL(k_coarse_pupdate, dim3(nb), dim3(256), 0, L.stream, A, p, z, L.scal, slot_old, slot_new,
+                       L.partials + 1024, nb);
     check_launch();
-    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, L.stream, L.scal, (int)S_C0, (int)S_C3);
+}
+// r.r of the last update -> scal[S_TMP] (convergence check)
+void launch_coarse_residual_norm(const Launch &L, const CoarseDev &A)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, coarse_blocks(L, A.n), L.scal,
+                       (int)S_TMP);
     check_launch();
 }
 
