@@ -714,16 +714,20 @@ k_iface_faces(const int32_t *__restrict__ pairs, int64_t npairs, int nfi, int of
     }
 }
 
-// CSR entities (edges: per = nei at offset off_edge + lid*nei; nodes: per = 1 at offset lid)
+// CSR entities in one launch: shared edges (nei values at offset off_edge + lid*nei) followed by shared nodes (one
+// value at offset lid).  Copies are summed in list order (ascending cell, the reference's order).
 __global__ void __launch_bounds__(256)
-k_iface_csr(const int32_t *__restrict__ ptr, const int32_t *__restrict__ ent, int64_t nent, int per, int off, int ld,
-            double *x)
+k_iface_csr(const int32_t *__restrict__ eptr, const int32_t *__restrict__ eent, int64_t nedge, int nei, int off_edge,
+            const int32_t *__restrict__ nptr, const int32_t *__restrict__ nent, int64_t nnode, int ld, double *x)
 {
-    const int64_t total = nent * per;
+    const int64_t tedge = nedge * nei, total = tedge + nnode;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = idx / per;
-        const int k = (int)(idx - e * per);
+        const bool is_edge = idx < tedge;
+        const int64_t e = is_edge ? idx / nei : idx - tedge;
+        const int k = is_edge ? (int)(idx - e * nei) : 0;
+        const int per = is_edge ? nei : 1, off = is_edge ? off_edge : 0;
+        const int32_t *ptr = is_edge ? eptr : nptr, *ent = is_edge ? eent : nent;
         const int b = ptr[e], end = ptr[e + 1];
         double s = 0.0;
         for (int q = b; q < end; ++q) {
@@ -752,21 +756,17 @@ void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &me
         first = which == 2 ? ncut : 0;
         count = which == 1 ? ncut : which == 2 ? n - ncut : n;
     };
-    int64_t first, count;
-    range(mesh.nsharededges, mesh.ncut_edge_groups, first, count);
-    if (lv.nei > 0 && count > 0) {
-        int64_t blocks = (count * lv.nei + 255) / 256;
+    int64_t efirst, ecount, nfirst, ncount;
+    range(mesh.nsharededges, mesh.ncut_edge_groups, efirst, ecount);
+    range(mesh.nsharednodes, mesh.ncut_node_groups, nfirst, ncount);
+    if (lv.nei == 0) ecount = 0;
+    const int64_t total = ecount * lv.nei + ncount;
+    if (total > 0) {
+        int64_t blocks = (total + 255) / 256;
         if (blocks > cap * 4) blocks = cap * 4;
-        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.edge_ptr + first,
-                           mesh.edge_ent, count, lv.nei, lv.off_edge, lv.ld, x);
-        check_launch();
-    }
-    range(mesh.nsharednodes, mesh.ncut_node_groups, first, count);
-    if (count > 0) {
-        int64_t blocks = (count + 255) / 256;
-        if (blocks > cap * 4) blocks = cap * 4;
-        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.node_ptr + first,
-                           mesh.node_ent, count, 1, 0, lv.ld, x);
+        hipLaunchKernelGGL(k_iface_csr, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.edge_ptr + efirst,
+                           mesh.edge_ent, ecount, lv.nei, lv.off_edge, mesh.node_ptr + nfirst, mesh.node_ent, ncount,
+                           lv.ld, x);
         check_launch();
     }
 }
