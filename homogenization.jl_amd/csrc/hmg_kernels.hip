@@ -630,9 +630,12 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     }
     const int nf = lv.nf;
     int nt = L.apply_threads;
-    if (nt == 0) nt = nf <= 64 ? 64 : nf <= 2048 ? 256 : 1024;
+    // (small cells are bound by the number of waves launched, not by their work: as few waves per cell as hold it)
+    if (nt == 0) nt = nf <= 64 ? 64 : nf <= 192 ? 192 : nf <= 2048 ? 256 : 1024;
     if (nt <= 64)
         launch_apply_generic<DIM, 64, 1, FUSED>(L, lv, mesh, a, lds);
+    else if (nt <= 192 && nf <= 192)
+        launch_apply_generic<DIM, 192, 1, FUSED>(L, lv, mesh, a, lds);
     else if (nt <= 256 && nf <= 1024)
         launch_apply_generic<DIM, 256, 4, FUSED>(L, lv, mesh, a, lds);
     else if (nt <= 256)
