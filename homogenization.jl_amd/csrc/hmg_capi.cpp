@@ -64,7 +64,7 @@ struct LevelBufs {
     DevBuf<uint16_t> slab_cp_slot, slab_rs_slot;
     DevBuf<double> rtab;   // restriction weights in class-table layout (slab levels)
     int nslab = 0, slab_lds_nodes = 0;
-    DevBuf<uint32_t> pos32, pos32w, sweep32;
+    DevBuf<uint32_t> pos32, pos32w, sweep32, par32;
     DevBuf<double> ctab;
     DevBuf<int32_t> hier2slot, par_a, par_b, rptr, ridx;
     DevBuf<double> dphi;
@@ -94,6 +94,7 @@ struct hmg_ctx {
     bool fuse_cg_default = true;
     bool fold_x = true;   // V-cycle: pre-smoother's last x-update rides with the local residual
     bool swap_rp = true;  // V-cycle: step 0 of a smoother takes r itself as p (pointer exchange), see smooth()
+    bool fold_prolong = true;   // V-cycle: prolongation folded into the post-smoother's first residual
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -430,6 +431,15 @@ static void upload_levels(hmg_grid *g)
             B.ctab.upload(T.ctab, s);
             B.hier2slot.upload(T.hier2slot, s);
             B.par_a.upload(T.par_a, s);
+            {
+                std::vector<uint32_t> pp(T.par_a.size());
+                for (size_t q = 0; q < pp.size(); ++q) {
+                    if ((uint32_t)T.par_a[q] > 0xffffu || (uint32_t)T.par_b[q] > 0xffffu)
+                        throw std::runtime_error("coarse slot exceeds 16 bits");
+                    pp[q] = (uint32_t)T.par_a[q] | ((uint32_t)T.par_b[q] << 16);
+                }
+                B.par32.upload(pp, s);
+            }
             B.par_b.upload(T.par_b, s);
             B.rptr.upload(T.rptr, s);
             B.ridx.upload(T.ridx, s);
@@ -466,6 +476,7 @@ static void upload_levels(hmg_grid *g)
         D.ctab = B.ctab.p;
         D.hier2slot = B.hier2slot.p;
         D.par_a = B.par_a.p;
+        D.par32 = B.par32.p;
         D.par_b = B.par_b.p;
         D.rptr = B.rptr.p;
         D.ridx = B.ridx.p;
@@ -609,7 +620,7 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     set_slab(g, lv);
     // algorithmic HBM streams of this launch: x in, out, + src, + x2 (p_old), + xout (p), + xacc (x read and write)
     const double streams = 1.0 + (a.out ? 1.0 : 0.0) + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) +
-                           (a.xacc ? 2.0 : 0.0);
+                           (a.xacc ? 2.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
     const int64_t ncut = g->exchange || g->ex_begin ? cut_doubles(g, lv) : 0;
     const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 && g->md.ncells_cut > 0;
@@ -623,7 +634,7 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
             launch_apply_args(L, lv, g->md, b);
     };
     auto sums = [&]() {
-        if (!fused) return;
+        if (!fused || slot_pap < 0) return;
         launch_apply_fused_reduce(L, g->md, slot_pap, slot_rr);
         if (slot_rr >= 0) scalar_sum(g, slot_rr, 1);
         scalar_sum(g, slot_pap, 1);
@@ -674,8 +685,10 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
 // into the other buffer and the device pointers of the two handles are exchanged (8 B/DOF less at step 0).  Only
 // for callers that smooth a level an even number of times before anybody looks at the handles' memory (vcycle: pre-
 // and post-smoother), so that wrapped external buffers end up holding what their names say.
+// xcoarse (fused path, cells that fit the LDS): x += P xcoarse (the coarse-grid correction, src/multigrid.jl:113) is
+// applied in the load phase of the first residual instead of by a separate prolongation pass.
 int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
-           bool live_tail = true, bool defer_x = false, bool swap_rp = false)
+           bool live_tail = true, bool defer_x = false, bool swap_rp = false, const hmg_vec *xcoarse = nullptr)
 {
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
@@ -689,7 +702,14 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
         a.src = b->d;
         a.out = r->d;
         a.flags = 1;
-        apply_then_sum(g, lv, a, false, -1, -1);
+        if (xcoarse) {
+            a.xcoarse = xcoarse->d;
+            a.ldc = lev(g, level - 1).ld;
+            a.xout = x->d;
+            apply_then_sum(g, lv, a, true, -1, -1);
+        } else {
+            apply_then_sum(g, lv, a, false, -1, -1);
+        }
     }
     int cur = S_RS, other = S_RS2;
     if (g->fuse_cg) {
@@ -891,8 +911,12 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     restrict_level(g, k, cur[2]->d, nxt[1]->d);
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st);
-    launch_prolong_add(L, lev(g, k), lev(g, k - 1), g->md.ncells, nxt[0]->d, cur[0]->d);
-    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], true, false, swap_rp);
+    // coarse-grid correction: folded into the post-smoother's first residual where the fused kernel can hold the
+    // coarse column in LDS next to the lattice image (two workgroups per CU must still fit), else a separate pass
+    const bool fold_p = g->ctx->fold_prolong && g->fuse_cg && apply_lds_bytes(lev(g, k)) <= 160 * 1024 &&
+                        apply_lds_bytes(lev(g, k)) + sizeof(double) * (size_t)lev(g, k - 1).nf <= 80 * 1024;
+    if (!fold_p) launch_prolong_add(L, lev(g, k), lev(g, k - 1), g->md.ncells, nxt[0]->d, cur[0]->d);
+    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], true, false, swap_rp, fold_p ? nxt[0] : nullptr);
 }
 
 // ---- multi-GPU cut exchange -------------------------------------------------------------------
@@ -1028,6 +1052,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->fold_x = value != 0;
     else if (n == "swap_rp")
         ctx->swap_rp = value != 0;
+    else if (n == "fold_prolong")
+        ctx->fold_prolong = value != 0;
     else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
         ctx->timer.on = value > 0;
         ctx->timer.min_level = (int)value;

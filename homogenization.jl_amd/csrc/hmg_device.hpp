@@ -30,6 +30,7 @@ struct LevelDev {
     const double *ctab;            // [ncls*ndir*nterm]
     const int32_t *hier2slot;      // [nf]
     const int32_t *par_a, *par_b;  // [nf]     (level > 1)
+    const uint32_t *par32;         // [nf]     par_a | par_b << 16 (coarse storage slots; level > 1)
     const int32_t *rptr, *ridx;    // [nf_coarse+1], [..] (level > 1)
     const double *dphi;            // [3*nf]
 };
@@ -72,6 +73,8 @@ struct ApplyArgs {
     double *xout;          // optional: xin written back (p-update / p = r)
     double *xacc;          // optional: xacc += (scal[a_num] / scal[a_den]) * x2  (the previous step's x-update)
     int a_num, a_den;
+    const double *xcoarse; // optional (fused kernel, not the slab one): xin = x + P xcoarse first (prolongation of the
+    int64_t ldc;           //   coarse-grid correction; column stride ldc), written back through xout
     const double *src;     // optional: out = src + alpha * A * xin
     double *out;
     const double *scal;

@@ -259,11 +259,28 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         double *xac = FUSED && a.xacc ? a.xacc + cell * lv.ld : nullptr;
         const double beta = x2c ? a.scal[a.s_num] / a.scal[a.s_den] : 0.0;
         const double ax = xac ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0;
+        // FUSED, optional: the prolongation of the coarse-grid correction, xin = x + P xcoarse (interpolate_and_sum_to!,
+        // src/interpolation.jl:64-74: identity rows += 1.0 c[a], midpoints += 0.5 c[a], += 0.5 c[b] in the CSC
+        // column order), from the cell's coarse column staged in LDS behind the lattice image
+        const double *ccol = FUSED && a.xcoarse ? a.xcoarse + cell * a.ldc : nullptr;
+        double *cs = xs + nf + lv.lds_g1;
+        double cval = 0.0;
+        if (ccol) {
+            if (tid < lv.nf_coarse) cval = ccol[tid];
+            for (int q = tid + NT; q < lv.nf_coarse; q += NT) cs[q] = ccol[q];
+        }
+        auto prolong = [&](double v, uint32_t w) {
+            const uint32_t pa = w & 0xffffu, pb = w >> 16;
+            if (pa == pb) return v + cs[pa];
+            v += 0.5 * cs[pa];
+            return v + 0.5 * cs[pb];
+        };
         constexpr int HB = FUSED ? (SPT + 1) / 2 : SPT;
 #pragma unroll
         for (int q0 = 0; q0 < SPT; q0 += HB) {
             double xv[HB], x2v[HB], xav[HB];
             int lp[HB];
+            uint32_t pw[HB];
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
                 const int t = tid + (q0 + q) * NT;
@@ -272,7 +289,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     x2v[q] = x2c ? x2c[t] : 0.0;
                     xav[q] = xac ? xac[t] : 0.0;
                     lp[q] = lv.lpos[t];
+                    if (FUSED) pw[q] = ccol ? lv.par32[t] : 0u;
                 }
+            }
+            if (FUSED && q0 == 0 && ccol) {   // coarse column complete before the first use
+                if (tid < lv.nf_coarse) cs[tid] = cval;
+                __syncthreads();
             }
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
@@ -280,6 +302,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 if (q0 + q < SPT && t < nf) {
                     double v = xv[q];
                     if (FUSED) {
+                        if (ccol) v = prolong(v, pw[q]);
                         if (xac) xac[t] = xav[q] + ax * x2v[q];
                         if (x2c) v = v + beta * x2v[q];
                         if (xoc) xoc[t] = v;
@@ -293,6 +316,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             double v = xc[t];
             if (FUSED) {
                 const double pv = x2c ? x2c[t] : 0.0;
+                if (ccol) v = prolong(v, lv.par32[t]);
                 if (xac) xac[t] = xac[t] + ax * pv;
                 if (x2c) v = v + beta * pv;
                 if (xoc) xoc[t] = v;
@@ -604,6 +628,7 @@ template <int DIM, int NT, int SPT, bool FUSED>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
     auto kern = k_apply<DIM, NT, SPT, FUSED>;
+    if (FUSED && a.xcoarse) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t nblocks = a.cell_list ? a.ncell_list : mesh.ncells;
