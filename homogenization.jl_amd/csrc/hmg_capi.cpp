@@ -95,6 +95,7 @@ struct hmg_ctx {
     bool fold_x = true;   // V-cycle: pre-smoother's last x-update rides with the local residual
     bool swap_rp = true;  // V-cycle: step 0 of a smoother takes r itself as p (pointer exchange), see smooth()
     bool fold_prolong = true;   // V-cycle: prolongation folded into the post-smoother's first residual
+    bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -620,7 +621,7 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     set_slab(g, lv);
     // algorithmic HBM streams of this launch: x in, out, + src, + x2 (p_old), + xout (p), + xacc (x read and write)
     const double streams = 1.0 + (a.out ? 1.0 : 0.0) + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) +
-                           (a.xacc ? 2.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
+                           (a.xacc ? 2.0 : 0.0) + (a.x3 ? 1.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
     const int64_t ncut = g->exchange || g->ex_begin ? cut_doubles(g, lv) : 0;
     const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 && g->md.ncells_cut > 0;
@@ -673,6 +674,16 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     cut_pack(g, lv, a.out, 1);
 }
 
+// What a pre-smoother leaves to its caller when defer_x is set (see smooth()).
+struct DeferredX {
+    int rs = -1;         // >= 0: x += (scal[rs] / scal[pap]) * p_last is still to be done
+    int pap = S_PAP;
+    // lazy form (two_updates): p_last itself was not formed either.  With p1 = the p handle, r2 = the r handle:
+    //   x += (scal[a_num]/scal[a_den]) p1;  p2 = r2 + (scal[b_num]/scal[b_den]) p1;  x += (scal[rs]/scal[pap]) p2
+    bool two_updates = false;
+    int a_num = -1, a_den = -1, b_num = -1, b_den = -1;
+};
+
 // live_tail = false drops the work of the last CG step whose results nobody can read: inside a V-cycle the
 // pre-smoother's r, p and Ap are overwritten (local residual, post-smoother's `p = r`, its first `Ap`) before
 // control returns to the caller, so of step `steps-1` only alpha = rs / p.Ap and x += alpha p are live -- the
@@ -687,9 +698,13 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
 // and post-smoother), so that wrapped external buffers end up holding what their names say.
 // xcoarse (fused path, cells that fit the LDS): x += P xcoarse (the coarse-grid correction, src/multigrid.jl:113) is
 // applied in the load phase of the first residual instead of by a separate prolongation pass.
-int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
-           bool live_tail = true, bool defer_x = false, bool swap_rp = false, const hmg_vec *xcoarse = nullptr)
+// With defer_x and lazy (cells that fit the LDS) a dead last step i > 0 writes nothing at all: it forms p_i only in
+// LDS for the operator apply and the p.Ap reduction, and leaves both pending x-updates to the caller (DeferredX).
+DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
+                 bool live_tail = true, bool defer_x = false, bool swap_rp = false, const hmg_vec *xcoarse = nullptr,
+                 bool lazy = false)
 {
+    DeferredX none;
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
     const Launch &L = g->ctx->L;
@@ -725,9 +740,10 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
             a.alpha = 1.0;
             a.lambda = g->lambda;
             a.x = r->d;
+            const bool lazy_dead = dead && defer_x && lazy && i > 0 && apply_lds_bytes(lv) <= 160 * 1024;
             a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
-            a.xout = i == 0 && swap_rp ? nullptr : p->d;                  // (swap_rp: r_0 itself becomes p_0)
-            a.xacc = i == 0 ? nullptr : x->d;                             // x += alpha_{i-1} p_{i-1}
+            a.xout = (i == 0 && swap_rp) || lazy_dead ? nullptr : p->d;   // (swap_rp: r_0 itself becomes p_0)
+            a.xacc = i == 0 || lazy_dead ? nullptr : x->d;                // x += alpha_{i-1} p_{i-1}
             a.a_num = other;                                              // rs_{i-1} (after the swap below)
             a.a_den = S_PAP;                                              // p_{i-1}.Ap_{i-1}: still the old value here
             a.out = dead ? nullptr : Ap->d;
@@ -736,6 +752,20 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
             a.flags = 1;
             // (the kernels above read the previous p.Ap from S_PAP; the reduction that overwrites it is enqueued
             //  behind them on the same stream)
+            if (lazy_dead) {
+                // p.Ap of this step goes to its own slot: S_PAP still holds the previous step's, which the caller
+                // needs for the first of the two pending x-updates
+                apply_then_sum(g, lv, a, true, S_PAP2, -1);
+                DeferredX d;
+                d.rs = cur;
+                d.pap = S_PAP2;
+                d.two_updates = true;
+                d.a_num = other;   // rs_{i-1}
+                d.a_den = S_PAP;   // p_{i-1}.Ap_{i-1}
+                d.b_num = cur;     // beta_i = rs_i / rs_{i-1}
+                d.b_den = other;
+                return d;
+            }
             apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1);
             const double *r_in = r->d;
             if (i == 0 && swap_rp) {
@@ -745,9 +775,13 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
                 r_in = p->d;
             }
             if (dead) {
-                if (defer_x) return cur;
+                if (defer_x) {
+                    DeferredX d;
+                    d.rs = cur;
+                    return d;
+                }
                 launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);   // x += (rs / p.Ap) p
-                return -1;
+                return none;
             }
             launch_cg_rupdate(L, r_in, r->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs / p.Ap
             scalar_sum(g, other, 1);
@@ -761,7 +795,7 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
             launch_copy_dot(L, p->d, r->d, n, cur);
             scalar_sum(g, cur, 1);
         }
-        return -1;
+        return none;
     }
     launch_copy_dot(L, p->d, r->d, n, cur);                              // p = r; rs = r.r
     scalar_sum(g, cur, 1);
@@ -772,14 +806,14 @@ int smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r
         scalar_sum(g, S_PAP, 1);
         if (!live_tail && i == steps - 1) {
             launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);       // x += (rs / p.Ap) p
-            return -1;
+            return none;
         }
         launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs/pAp
         scalar_sum(g, other, 1);
         launch_cg_pupdate(L, p->d, r->d, n, other, cur);                       // beta = rs'/rs
         std::swap(cur, other);
     }
-    return -1;
+    return none;
 }
 
 void coarse_setup(hmg_grid *g)
@@ -888,19 +922,30 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     const Launch &L = g->ctx->L;
     // (an odd number of pointer exchanges would leave r and p swapped: both smoother calls take the same `steps`)
     const bool swap_rp = g->ctx->swap_rp && g->fuse_cg && steps > 0;
-    const int rs_slot = smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false,
-                               /*defer_x=*/g->ctx->fold_x, swap_rp);
-    if (rs_slot >= 0) {
-        // local residual with the pre-smoother's last x-update folded into its load phase:
-        // x += alpha p (written back), r = b - A x; 40 B/DOF instead of 24 + 24
+    const DeferredX dx = smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false,
+                                /*defer_x=*/g->ctx->fold_x, swap_rp, nullptr, /*lazy=*/g->ctx->lazy_dead);
+    if (dx.rs >= 0) {
+        // local residual with the pre-smoother's pending x-update(s) folded into its load phase (x written back),
+        // r = b - A x: 40 B/DOF instead of 24 + 24; in the lazy form the dead step wrote neither x nor p (16 B/DOF
+        // instead of 40) and this pass reads r as well (48 B/DOF)
         ApplyArgs a{};
         a.alpha = -1.0;
         a.lambda = g->lambda;
         a.x = cur[0]->d;
         a.x2 = cur[3]->d;
         a.xout = cur[0]->d;
-        a.s_num = rs_slot;
-        a.s_den = S_PAP;
+        if (dx.two_updates) {
+            a.x3 = cur[2]->d;
+            a.a_num = dx.a_num;
+            a.a_den = dx.a_den;
+            a.s_num = dx.b_num;
+            a.s_den = dx.b_den;
+            a.c_num = dx.rs;
+            a.c_den = dx.pap;
+        } else {
+            a.s_num = dx.rs;
+            a.s_den = dx.pap;
+        }
         a.src = cur[1]->d;
         a.out = cur[2]->d;
         a.flags = 1;
@@ -1054,6 +1099,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->swap_rp = value != 0;
     else if (n == "fold_prolong")
         ctx->fold_prolong = value != 0;
+    else if (n == "lazy_dead")
+        ctx->lazy_dead = value != 0;
     else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
         ctx->timer.on = value > 0;
         ctx->timer.min_level = (int)value;

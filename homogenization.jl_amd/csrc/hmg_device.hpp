@@ -73,6 +73,8 @@ struct ApplyArgs {
     double *xout;          // optional: xin written back (p-update / p = r)
     double *xacc;          // optional: xacc += (scal[a_num] / scal[a_den]) * x2  (the previous step's x-update)
     int a_num, a_den;
+    const double *x3;      // optional (k_apply FUSED, with x2, without xacc): xin = (x + ax*x2) + c*(x3 + beta*x2),
+    int c_num, c_den;      //   ax = scal[a_num]/scal[a_den], c = scal[c_num]/scal[c_den]: two CG x-updates at once
     const double *xcoarse; // optional (fused kernel, not the slab one): xin = x + P xcoarse first (prolongation of the
     int64_t ldc;           //   coarse-grid correction; column stride ldc), written back through xout
     const double *src;     // optional: out = src + alpha * A * xin
@@ -96,7 +98,7 @@ struct CoarseDev {
 };
 
 // scalar bank slots (device doubles)
-enum { S_RS = 0, S_PAP = 1, S_RS2 = 2, S_TMP = 3, S_C0 = 4, S_C1 = 5, S_C2 = 6, S_C3 = 7, S_COUNT = 16 };
+enum { S_RS = 0, S_PAP = 1, S_RS2 = 2, S_TMP = 3, S_C0 = 4, S_C1 = 5, S_C2 = 6, S_C3 = 7, S_PAP2 = 8, S_COUNT = 16 };
 
 struct Launch {
     hipStream_t stream;

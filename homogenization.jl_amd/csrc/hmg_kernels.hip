@@ -257,8 +257,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         const double *x2c = FUSED && a.x2 ? a.x2 + cell * lv.ld : nullptr;
         double *xoc = FUSED && a.xout ? a.xout + cell * lv.ld : nullptr;
         double *xac = FUSED && a.xacc ? a.xacc + cell * lv.ld : nullptr;
+        // x3 mode (two pending CG x-updates folded into a residual): xin = (x + ax*p1) + c2*(r2 + beta*p1), x2 = p1,
+        // x3 = r2; the same three roundings as x += ax*p1; p2 = r2 + beta*p1; x += c2*p2 done one after the other
+        const double *x3c = FUSED && a.x3 ? a.x3 + cell * lv.ld : nullptr;
         const double beta = x2c ? a.scal[a.s_num] / a.scal[a.s_den] : 0.0;
-        const double ax = xac ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0;
+        const double ax = xac || x3c ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0;
+        const double c2 = x3c ? a.scal[a.c_num] / a.scal[a.c_den] : 0.0;
         // FUSED, optional: the prolongation of the coarse-grid correction, xin = x + P xcoarse (interpolate_and_sum_to!,
         // src/interpolation.jl:64-74: identity rows += 1.0 c[a], midpoints += 0.5 c[a], += 0.5 c[b] in the CSC
         // column order), from the cell's coarse column staged in LDS behind the lattice image
@@ -287,7 +291,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 if (q0 + q < SPT && t < nf) {
                     xv[q] = xc[t];
                     x2v[q] = x2c ? x2c[t] : 0.0;
-                    xav[q] = xac ? xac[t] : 0.0;
+                    xav[q] = xac ? xac[t] : x3c ? x3c[t] : 0.0;
                     lp[q] = lv.lpos[t];
                     if (FUSED) pw[q] = ccol ? lv.par32[t] : 0u;
                 }
@@ -304,7 +308,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     if (FUSED) {
                         if (ccol) v = prolong(v, pw[q]);
                         if (xac) xac[t] = xav[q] + ax * x2v[q];
-                        if (x2c) v = v + beta * x2v[q];
+                        if (x3c) {
+                            const double t1 = v + ax * x2v[q];
+                            const double p2 = xav[q] + beta * x2v[q];
+                            v = t1 + c2 * p2;
+                        } else if (x2c)
+                            v = v + beta * x2v[q];
                         if (xoc) xoc[t] = v;
                         rr += v * v;
                     }
@@ -318,7 +327,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 const double pv = x2c ? x2c[t] : 0.0;
                 if (ccol) v = prolong(v, lv.par32[t]);
                 if (xac) xac[t] = xac[t] + ax * pv;
-                if (x2c) v = v + beta * pv;
+                if (x3c) {
+                    const double t1 = v + ax * pv;
+                    const double p2 = x3c[t] + beta * pv;
+                    v = t1 + c2 * p2;
+                } else if (x2c)
+                    v = v + beta * pv;
                 if (xoc) xoc[t] = v;
                 rr += v * v;
             }

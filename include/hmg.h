@@ -43,10 +43,11 @@ int hmg_ctx_create_on_stream(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_destroy(hmg_ctx *ctx);
 int hmg_ctx_sync(hmg_ctx *ctx);
 /* option names: "apply_threads" (workgroup size of the apply kernel, 0 = auto), "fuse_cg" (1 = fused CG pass,
- * default; read when a grid is created), "fold_x" / "swap_rp" / "fold_prolong" (1 = default: hmg_vcycle folds the
- * pre-smoother's last x-update into the local residual / lets CG step 0 take r itself as p by exchanging the two
- * handles' device pointers / folds the prolongation into the post-smoother's first residual -- exact savings,
- * results unchanged; 0 = the plain sequence), "coarse_maxit", "coarse_check",
+ * default; read when a grid is created), "fold_x" / "lazy_dead" / "swap_rp" / "fold_prolong" (1 = default: hmg_vcycle
+ * folds the pre-smoother's last x-update into the local residual / lets the pre-smoother's last step write nothing
+ * and folds both pending x-updates / lets CG step 0 take r itself as p by exchanging the two handles' device
+ * pointers / folds the prolongation into the post-smoother's first residual -- exact savings, results unchanged;
+ * 0 = the plain sequence), "coarse_maxit", "coarse_check",
  * "time_apply"; "coarse_rtol" via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
  * kernel for cells larger than the LDS, default 70). */
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
