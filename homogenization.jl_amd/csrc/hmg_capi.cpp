@@ -698,7 +698,7 @@ struct DeferredX {
 // and post-smoother), so that wrapped external buffers end up holding what their names say.
 // xcoarse (fused path, cells that fit the LDS): x += P xcoarse (the coarse-grid correction, src/multigrid.jl:113) is
 // applied in the load phase of the first residual instead of by a separate prolongation pass.
-// With defer_x and lazy (cells that fit the LDS) a dead last step i > 0 writes nothing at all: it forms p_i only in
+// With defer_x and lazy a dead last step i > 0 writes nothing at all: it forms p_i only in
 // LDS for the operator apply and the p.Ap reduction, and leaves both pending x-updates to the caller (DeferredX).
 DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
                  bool live_tail = true, bool defer_x = false, bool swap_rp = false, const hmg_vec *xcoarse = nullptr,
@@ -740,7 +740,7 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             a.alpha = 1.0;
             a.lambda = g->lambda;
             a.x = r->d;
-            const bool lazy_dead = dead && defer_x && lazy && i > 0 && apply_lds_bytes(lv) <= 160 * 1024;
+            const bool lazy_dead = dead && defer_x && lazy && i > 0;
             a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
             a.xout = (i == 0 && swap_rp) || lazy_dead ? nullptr : p->d;   // (swap_rp: r_0 itself becomes p_0)
             a.xacc = i == 0 || lazy_dead ? nullptr : x->d;                // x += alpha_{i-1} p_{i-1}

@@ -470,8 +470,10 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     const double *x2c = FUSED && a.x2 ? a.x2 + cell * lv.ld : nullptr;
     double *xoc = FUSED && a.xout ? a.xout + cell * lv.ld : nullptr;
     double *xac = FUSED && a.xacc ? a.xacc + cell * lv.ld : nullptr;
+    const double *x3c = FUSED && a.x3 ? a.x3 + cell * lv.ld : nullptr;   // two pending x-updates, see k_apply
     const double beta = to_sgpr(x2c ? a.scal[a.s_num] / a.scal[a.s_den] : 0.0);
-    const double ax = to_sgpr(xac ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0);
+    const double ax = to_sgpr(xac || x3c ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0);
+    const double c2 = to_sgpr(x3c ? a.scal[a.c_num] / a.scal[a.c_den] : 0.0);
     const uint32_t dm = (a.flags & 1) ? dmask[cell] : 0u;
     const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
     double *oc = a.out ? a.out + cell * (a.out_ld ? a.out_ld : (int64_t)lv.ld) : nullptr;
@@ -531,7 +533,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
                     const int t = (int)(wd[q] >> 16);
                     xv[q] = xc[t];
                     x2v[q] = x2c ? x2c[t] : 0.0;
-                    xav[q] = xac ? xac[t] : 0.0;
+                    xav[q] = xac ? xac[t] : x3c ? x3c[t] : 0.0;
                 }
             }
 #pragma unroll
@@ -542,7 +544,12 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
                     double val = xv[q];
                     if (FUSED) {
                         if (xac) xac[t] = xav[q] + ax * x2v[q];
-                        if (x2c) val = val + beta * x2v[q];
+                        if (x3c) {
+                            const double t1 = val + ax * x2v[q];
+                            const double p2 = xav[q] + beta * x2v[q];
+                            val = t1 + c2 * p2;
+                        } else if (x2c)
+                            val = val + beta * x2v[q];
                         if (xoc) xoc[t] = val;
                         rr += val * val;
                     }
