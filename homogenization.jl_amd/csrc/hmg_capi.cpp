@@ -221,7 +221,7 @@ void upload_mesh(hmg_grid *g)
     g->d_dupmask.upload(M.dupmask, s);
     g->d_mult.upload(M.mult, s);
 #ifdef HMG_PHASE_TIMING
-    constexpr size_t BP = 8;   // 8 time stamps per workgroup
+    constexpr size_t BP = 10;   // 2 reduction partials + 8 time stamps per workgroup
 #else
     constexpr size_t BP = 2;
 #endif

@@ -209,8 +209,9 @@ __device__ __forceinline__ void decode32w(uint32_t w, int m, int &L, int &len, i
 //                p is identical in all copies of a shared DOF (src/multigrid.jl:54-68)
 #ifdef HMG_PHASE_TIMING   // dev build (make phase-timing): thread 0 of every workgroup stamps its phases into blockpart
 #define HMG_STAMP(i)                                                                     \
-    do {                                                                                 \
-        if (!FUSED && a.blockpart && tid == 0) a.blockpart[8 * cell + (i)] = (double)wall_clock64(); \
+    do {   /* stamps behind the 2 * ncells reduction partials (full-grid launches only) */ \
+        if (a.blockpart && !a.cell_list && tid == 0)                                     \
+            a.blockpart[2 * (size_t)gridDim.x + 8 * cell + (i)] = (double)wall_clock64(); \
     } while (0)
 #else
 #define HMG_STAMP(i)
@@ -427,6 +428,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             a.blockpart[2 * cell + 1] = s_rr;
         }
     }
+    HMG_STAMP(6);
 }
 
 // Slab variant for cells whose lattice image exceeds the LDS (level 7 in 3D: 374 KiB).  The cell is processed in

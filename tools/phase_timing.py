@@ -2,7 +2,7 @@
 """Where does a k_apply workgroup spend its life?  Runs the finest-level operator apply from the dev build
 `make -C homogenization.jl_amd/csrc phase-timing` (libhmg_hip_phase_timing.so: thread 0 of every workgroup stamps
 wall_clock64(), 100 MHz, at 6 points) and prints the mean duration of each phase.
-  python tools/phase_timing.py [--mode ap|res] [--width 32] [--levels 6]
+  python tools/phase_timing.py [--mode ap|res|cg0|cg1] [--width 32] [--levels 6]
 """
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ from homogenization_jl_amd import _lib, driver
 ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=32)
 ap.add_argument("--levels", type=int, default=6)
-ap.add_argument("--mode", default="ap")
+ap.add_argument("--mode", default="ap", help="ap | res | cg0 (fused CG step 0: p = r stored, 24 B/DOF) | cg1 (fused CG step 1, 48 B/DOF)")
 a = ap.parse_args()
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhmg_hip_phase_timing.so")
 ctx = hmg.Context(0)
@@ -23,23 +23,32 @@ base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, a.width, L, seed
 x = hmg.DeviceMatrix(g, L).rand(1)
 y = hmg.DeviceMatrix(g, L).rand(2)
 z = hmg.DeviceMatrix(g, L).rand(3)
+if a.mode in ("cg0", "cg1"):
+    stt = hmg.LevelState(g, L)
+    stt.x.rand(1); stt.b.rand(2)
 for rep in range(3):
     if a.mode == "res":
         hmg.apply_ex(-1.0, g, x, y, z, constrain=True)
+    elif a.mode == "cg0":
+        hmg.smoothing_steps(1, g, op, stt, L)      # residual, then CG step 0 (stamps of the last apply launch survive)
+    elif a.mode == "cg1":
+        hmg.smoothing_steps(2, g, op, stt, L)      # ..., step 1 = full fused pass
     else:
         hmg.apply_ex(1.0, g, x, None, z, constrain=True)
 ctx.sync()
-st = g.table_f64("phase_stamps").reshape(-1, 8)[: g.ncells(), :6]
+raw = g.table_f64("phase_stamps")
+st = raw[2 * g.ncells():].reshape(-1, 8)[: g.ncells(), :7]
 tick = 10.0  # ns per wall_clock64 tick (100 MHz)
 d = np.diff(st, axis=1) * tick / 1e3
-names = ["W table + column load -> LDS", "table prefetch", "barrier wait", "surface loop", "interior loop"]
-print(f"workgroups {st.shape[0]}; kernel span {(st[:, 5].max() - st[:, 0].min()) * tick / 1e6:.3f} ms")
+names = ["W table + column load -> LDS", "table prefetch", "barrier wait", "surface loop", "interior loop",
+         "epilogue (reductions)"]
+print(f"workgroups {st.shape[0]}; kernel span {(st[:, 6].max() - st[:, 0].min()) * tick / 1e6:.3f} ms")
 for i, n in enumerate(names):
     print(f"  {n:32s} mean {d[:, i].mean():7.2f} us   p10 {np.percentile(d[:, i], 10):7.2f}   p90 {np.percentile(d[:, i], 90):7.2f}")
-life = (st[:, 5] - st[:, 0]) * tick / 1e3
+life = (st[:, 6] - st[:, 0]) * tick / 1e3
 print(f"  {'workgroup lifetime (stamped)':32s} mean {life.mean():7.2f} us")
 # slot turnaround: sort by start time; with 512 resident workgroups, start[i + 512] - end-ish
-s0 = np.sort(st[:, 0]); e5 = np.sort(st[:, 5])
+s0 = np.sort(st[:, 0]); e5 = np.sort(st[:, 6])
 nres = 512
 gap = (s0[nres:] - e5[:-nres]) * tick / 1e3
 print(f"  start of workgroup i+{nres} minus end of i (sorted): mean {gap.mean():7.2f} us  (launch + drain overhead per slot)")
