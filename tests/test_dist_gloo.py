@@ -153,7 +153,8 @@ def _worker(rank, world, port, dim, shape, levels, q):
 
 
 @pytest.mark.parametrize("world,dim,shape,levels", [(2, 3, (4, 2, 2), 4), (4, 3, (4, 4, 2), 3), (2, 2, (6, 3), 4),
-                                                      (3, 3, "delaunay", 3), (2, 2, "delaunay", 4)])
+                                                      (3, 3, "delaunay", 3), (2, 2, "delaunay", 4),
+                                                      (8, 3, (4, 4, 4), 3)])   # octants: centre node shared by 8 ranks
 def test_partitioned_interface_sum_matches_serial(world, dim, shape, levels):
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
