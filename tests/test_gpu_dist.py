@@ -90,7 +90,7 @@ def _worker(rank, world, port, width, levels, overlap, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,width,levels,overlap", [(2, 4, 4, True), (2, 4, 4, False), (2, 2, 7, True), (3, "delaunay3", 3, True),
+@pytest.mark.parametrize("world,width,levels,overlap", [(2, 4, 4, True), (2, 4, 4, False), (2, 2, 7, True), (4, 2, 4, True), (3, "delaunay3", 3, True),
                                                         (2, "delaunay2", 5, True), (2, "delaunay2", 5, False)])
 def test_multi_rank_vcycle_matches_serial_oracle(world, width, levels, overlap):
     """overlap=True: cut-adjacent cells first, asynchronous sum over ranks in flight during the rest."""
