@@ -8,7 +8,7 @@ module HomogenizationHIP
 using Homogenization
 import Homogenization: mul!, local_residual!, apply_constraint!, broadcast_interfaces!,
        zero_out_all_but_one!, restrict_to!, interpolate_and_sum_to!, smoothing_steps!, vcycle!,
-       copy_to_base!, distribute!, local_rhs!, LevelState, ImplicitFineGrid, L2PlusDivAGrad
+       copy_to_base!, distribute!, local_rhs!, rhs_aξ∇v!, next_rhs!, LevelState, ImplicitFineGrid, L2PlusDivAGrad
 import LinearAlgebra: dot, axpy!
 
 const LIB = get(ENV, "HMG_LIB", "libhmg_hip.so")
