@@ -134,6 +134,11 @@ struct hmg_grid {
     // multi-GPU
     std::unique_ptr<Partition> part;
     std::vector<double> sigma_global;
+    // inputs of the partition analysis, kept for a domain shrink (re-analysis of the prefix mesh)
+    std::vector<double> part_coords;
+    std::vector<int64_t> part_cells;
+    std::vector<int32_t> part_owner;
+    int64_t part_nnodes = 0, part_ncells = 0;
     DevBuf<int32_t> d_nodes_g, d_owned, d_cells_gnode;
     CutKind cut[3];   // faces, edges, nodes
     hmg_exchange_fn exchange = nullptr, scalar_sum = nullptr;
@@ -1178,6 +1183,22 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
 static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const int64_t *gid, const int32_t *cell_lid);
 static void upload_levels(hmg_grid *g);
 
+// device side of the partition tables (after upload_mesh): cut lists, node ownership, global node ids of the cells
+static void finish_partition(hmg_grid *g)
+{
+    const Partition &P = *g->part;
+    const MeshTables &M = g->cur();
+    for (int k = 0; k < 3; ++k) g->cut[k].nglobal = P.nglobal[k];
+    if (!g->ctx) return;
+    for (int k = 0; k < 3; ++k)
+        set_cut_kind(g, k, P.nglobal[k], (int64_t)P.gid[k].size(), P.gid[k].data(), P.cell_lid[k].data());
+    g->d_nodes_g.upload(P.nodes_g, g->ctx->stream);
+    g->d_owned.upload(P.owned_node, g->ctx->stream);
+    std::vector<int32_t> cg(M.cells.size());
+    for (size_t q = 0; q < cg.size(); ++q) cg[q] = P.nodes_g[M.cells[q]];
+    g->d_cells_gnode.upload(cg, g->ctx->stream);
+}
+
 int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
                               const int64_t *cells, const int32_t *owner, int rank, int nranks, hmg_grid **out)
 {
@@ -1192,21 +1213,14 @@ int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes
     g->lt = build_level_tables(dim, nlevels);
     g->part.reset(new Partition);
     build_partition(dim, nnodes, coords, ncells, cells, owner, rank, nranks, g->mesh_full, *g->part);
+    g->part_coords.assign(coords, coords + (size_t)dim * nnodes);
+    g->part_cells.assign(cells, cells + (size_t)(dim + 1) * ncells);
+    g->part_owner.assign(owner, owner + ncells);
+    g->part_nnodes = nnodes;
+    g->part_ncells = ncells;
     upload_levels(g.get());
     upload_mesh(g.get());
-    for (int k = 0; k < 3; ++k) g->cut[k].nglobal = g->part->nglobal[k];
-    if (ctx) {
-        const Partition &P = *g->part;
-        for (int k = 0; k < 3; ++k)
-            set_cut_kind(g.get(), k, P.nglobal[k], (int64_t)P.gid[k].size(), P.gid[k].data(), P.cell_lid[k].data());
-        g->d_nodes_g.upload(P.nodes_g, ctx->stream);
-        g->d_owned.upload(P.owned_node, ctx->stream);
-        const int N = dim + 1;
-        std::vector<int32_t> cg(g->mesh_full.cells.size());
-        for (size_t q = 0; q < cg.size(); ++q) cg[q] = P.nodes_g[g->mesh_full.cells[q]];
-        (void)N;
-        g->d_cells_gnode.upload(cg, ctx->stream);
-    }
+    finish_partition(g.get());
     *out = g.release();
     HMG_END
 }
@@ -1248,7 +1262,26 @@ int hmg_grid_shrink(hmg_grid *g, int64_t ncells_prefix, int64_t nnodes_prefix)
 {
     HMG_TRY
     need(g != nullptr, "null grid");
-    need(!g->part, "shrink on a partitioned grid is not supported yet");
+    if (g->part) {
+        // prefix of the GLOBAL mesh: this rank keeps its cells with a global id below the prefix length (local
+        // cells are in ascending global order, so that is a prefix of every local level vector as well); cut
+        // entities, Dirichlet masks, multiplicities and node ownership are re-derived from the smaller global mesh
+        need(ncells_prefix >= 1 && ncells_prefix <= g->part_ncells && nnodes_prefix >= 1 && nnodes_prefix <= g->part_nnodes,
+             "prefix out of range");
+        const int rank = g->part->rank, nranks = g->part->nranks;
+        std::unique_ptr<Partition> np(new Partition);
+        MeshTables local;
+        build_partition(g->dim, nnodes_prefix, g->part_coords.data(), ncells_prefix, g->part_cells.data(),
+                        g->part_owner.data(), rank, nranks, local, *np);
+        need(local.ncells <= g->mesh_full.ncells, "shrunk partition is larger than the original one");
+        g->mesh = std::move(local);
+        g->part = std::move(np);
+        g->shrunk = true;
+        upload_mesh(g);
+        finish_partition(g);
+        if (g->has_op) upload_operator(g);
+        return 0;
+    }
     restrict_mesh_tables(g->mesh_full, ncells_prefix, nnodes_prefix, g->mesh);
     g->shrunk = true;
     upload_mesh(g);
@@ -1740,7 +1773,7 @@ int hmg_integrate(hmg_grid *g, int mode, hmg_vec *v, hmg_vec *vprev, int64_t nce
 {
     HMG_TRY
     need(g && g->has_op && v && out, "null argument or operator not set");
-    need(!g->part, "driver integrals on a partitioned grid are not supported yet");
+    // (partitioned grid: the subset counts LOCAL cells and the result is this rank's share; the host sums over ranks)
     check_vec(g, v->level, v, "v");
     need(ncells_subset >= 0 && ncells_subset <= g->md.ncells, "subset out of range");
     const MeshTables &M = g->cur();

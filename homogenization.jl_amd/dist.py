@@ -58,6 +58,25 @@ class PartitionedGrid(api.ImplicitFineGrid):
     def exchange_doubles(self):
         return int(self._lib.hmg_grid_cut_buffer_doubles(self.h, 0))
 
+    def _refresh_local(self):
+        nodes = self.global_base.nodes
+        cells = self.global_base.elements
+        self.local_cells = self.table_i32("part_cells").astype(np.int64)     # global ids, ascending
+        self.local_nodes = self.table_i32("part_nodes").astype(np.int64)
+        inv = -np.ones(nodes.shape[0], dtype=np.int64)
+        inv[self.local_nodes] = np.arange(self.local_nodes.size)
+        self.base = api.Mesh(nodes[self.local_nodes], inv[cells[self.local_cells] - 1] + 1)
+
+    def shrink(self, ncells_prefix_global, nnodes_prefix_global):
+        """Domain shrink to a prefix of the GLOBAL cells / nodes: every rank keeps its cells below the prefix
+        length (a prefix of its own columns); cut entities, masks and ownership are re-derived by the library."""
+        L.check(self._lib.hmg_grid_shrink(self.h, int(ncells_prefix_global), int(nnodes_prefix_global)))
+        self._refresh_local()
+
+    def local_count_below(self, ncells_prefix_global):
+        """Number of this rank's cells with a global id below the given prefix length."""
+        return int(np.searchsorted(self.local_cells, ncells_prefix_global, side="left"))
+
 
 class Exchange:
     """Sum-over-ranks callbacks for one grid, on torch.distributed."""
@@ -186,3 +205,89 @@ def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int
     p.global_shape = "x".join(str(s) for s in shape)
     p.base_level = lambda: api.BaseLevel(grid)
     return p
+
+
+def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, rank: int, refinements: int = 2,
+                                            smoothing_steps: int = 3, tolerance: float = 1e-4, xi=None, seed: int = 0,
+                                            values=(1.0, 9.0), sigma_grid=None, x0=None, max_cycles: int = 1000,
+                                            group=None, log=None):
+    """driver.checkerboard_homogenization over `world` ranks (one GPU each): the base mesh is split into blocks about
+    the origin (halves / quadrants / octants for 2, 4, 8 ranks), so that the centred sub-domains the outer loop
+    shrinks to stay balanced.  Every rank runs the same host loop; the per-cycle integrals are local sums
+    added over the ranks, everything else goes through the partitioned V-cycle.  Returns (sigma, history) like the
+    single-GPU driver, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    dim = api._dim_of(eltype)
+    xi = driver.random_unit_vec(dim) if xi is None else np.asarray(xi, dtype=np.float64)
+    lam, sigma = 1.0, 0.0
+    box_radius = driver.compute_box_radius(0, n)
+    boundary_layer = driver.compute_boundary_layer(lam, n)
+    total_radius = box_radius + boundary_layer
+    width = 2 * total_radius
+    origin = (-float(total_radius),) * dim
+    base = driver.order_nodes_and_elements_by_magnitude(driver.hypercube(eltype, width, origin=origin))
+    if sigma_grid is None:
+        sigma_grid = driver.generate_conductivity(dim, width, seed, values)
+    cond = driver.conductivity_per_element(base, sigma_grid, (total_radius + 1.0,) * dim)
+    blocks = block_shape(world, dim)
+    owner = block_owner(base, blocks, width / 2.0, origin)          # halves per axis; axes with one block clamp to 0
+    total_grids = refinements + 1
+    grid = PartitionedGrid(ctx, base, total_grids, owner, rank, world)
+    Exchange(ctx, grid, group)
+    op = api.L2PlusDivAGrad(grid, lam, cond)
+    states = [api.LevelState(grid, i + 1) for i in range(total_grids)]
+    top = states[-1]
+    nf = grid.nf(total_grids)
+    if x0 is None:
+        x0 = api.host_random((nf, base.elements.shape[0]), seed + 1)       # hashed by GLOBAL cell id
+    top.x.from_host(np.asfortranarray(x0[:, grid.local_cells]))
+    api.broadcast_interfaces(top.x, grid, total_grids)
+    api.apply_constraint(top.x, total_grids, grid)
+    api.rhs_axi_grad_v(top.b, grid, xi)
+    v_prev = api.DeviceMatrix(grid, total_grids)
+    dev = torch.device("cuda", ctx.device)
+
+    def rank_sum(*vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, group=group)
+        return [float(v) for v in t.tolist()]
+
+    cur = base
+    history = []
+    for k in range(n + 1):
+        base_level = api.BaseLevel(grid)
+        dsig, dsig_prev = 0.0, 0.0
+        for i in range(1, max_cycles + 1):
+            api.vcycle(grid, base_level, [op] * total_grids, states, total_grids, smoothing_steps)
+            nint = grid.local_count_below(driver.find_elements_in_radius(cur, box_radius))
+            area = api.integrate_area(top.x, grid, nint)
+            if k == 0:
+                integral = api.integrate_first_term(top.x, grid, nint, xi)
+            else:
+                integral = api.integrate_terms(top.x, v_prev, grid, nint)
+            area, integral = rank_sum(area, integral)
+            dsig = 2.0 ** k * integral / area
+            rnorm = api.norm_unique(top.r)
+            history.append((k, i, rnorm, sigma + dsig, abs(dsig - dsig_prev)))
+            if log and rank == 0:
+                log(history[-1])
+            if abs(dsig - dsig_prev) < tolerance:
+                break
+            dsig_prev = dsig
+        sigma += dsig
+        lam /= 2
+        box_radius = driver.compute_box_radius(k + 1, n)
+        boundary_layer = driver.compute_boundary_layer(lam, n)
+        if box_radius + boundary_layer > total_radius:
+            break
+        total_radius = box_radius + boundary_layer
+        nn_keep = driver.find_nodes_in_radius(cur, total_radius)
+        ne_keep = driver.find_elements_in_radius(cur, total_radius)
+        cur = api.Mesh(cur.nodes[:nn_keep], np.ascontiguousarray(cur.elements[:ne_keep]))
+        grid.shrink(ne_keep, nn_keep)
+        api.apply_constraint(top.x, total_grids, grid)
+        v_prev.copyto(top.x)
+        op.lam = lam
+        api.next_rhs(top.b, top.x, grid)
+    return sigma, history

@@ -66,7 +66,9 @@ int hmg_grid_destroy(hmg_grid *grid);
 int hmg_grid_set_operator(hmg_grid *grid, const double *sigma /* dim*ncells */, double lambda);
 int hmg_grid_set_lambda(hmg_grid *grid, double lambda);
 /* Domain shrink to a prefix of cells / nodes + new Dirichlet boundary
- * (src/examples/homogenized_coefficients.jl:309-336).  Level vectors keep their storage. */
+ * (src/examples/homogenized_coefficients.jl:309-336).  Level vectors keep their storage.  On a partitioned grid
+ * the prefix lengths are GLOBAL; every rank keeps its cells below the prefix (a prefix of its own columns) and the
+ * cut entities, masks and ownership are re-derived. */
 int hmg_grid_shrink(hmg_grid *grid, int64_t ncells_prefix, int64_t nnodes_prefix);
 int64_t hmg_grid_ncells(const hmg_grid *grid);
 int64_t hmg_grid_nnodes(const hmg_grid *grid);
@@ -123,7 +125,8 @@ int hmg_rhs_axi_grad(hmg_grid *grid, const double *xi /* dim */, hmg_vec *b);
  * src/implicit_fine_grid.jl:391-409, used by checkerboard_hypercube_multigrid, ...homogenized_coefficients.jl:543) */
 int hmg_local_rhs(hmg_grid *grid, hmg_vec *b);
 /* integrate_first_term (mode 0, needs xi), integrate_terms (mode 1, needs vprev), integrate_area (mode 2) over
- * the first ncells_subset cells   (src/examples/homogenized_coefficients.jl:592-689) */
+ * the first ncells_subset cells   (src/examples/homogenized_coefficients.jl:592-689).  Partitioned grid: local
+ * cells, this rank's share of the integral (the host adds the shares). */
 int hmg_integrate(hmg_grid *grid, int mode, hmg_vec *v, hmg_vec *vprev, int64_t ncells_subset, const double *xi,
                   double *out);
 /* next_rhs!(b, x, implicit, ops): b = lambda*|J|*M*x  (src/examples/homogenized_coefficients.jl:695-713) */

@@ -106,3 +106,52 @@ def test_multi_rank_vcycle_matches_serial_oracle(world, width, levels, overlap):
         p.join(timeout=60)
     for rank, msg in sorted(res):
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _driver_worker(rank, world, port, n, dim, refinements, tol, q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        import homogenization_jl_amd as hmg
+        from homogenization_jl_amd import driver, dist as hdist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        ctx = hmg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        tag = hmg.Tri64 if dim == 2 else hmg.Tet64
+        width = 2 * (driver.compute_box_radius(0, n) + driver.compute_boundary_layer(1.0, n))
+        sgrid = driver.generate_conductivity(dim, width, 31)
+        want, hist_s = driver.checkerboard_homogenization(n, tag, refinements=refinements, tolerance=tol, ctx=ctx,
+                                                          sigma_grid=sgrid, seed=4)
+        got, hist_p = hdist.partitioned_checkerboard_homogenization(ctx, n, tag, world, rank, refinements=refinements,
+                                                                    tolerance=tol, sigma_grid=sgrid, seed=4)
+        assert [h[:2] for h in hist_p] == [h[:2] for h in hist_s], (hist_p[-1], hist_s[-1])
+        assert abs(got - want) <= 1e-10 * max(1.0, abs(want)), (got, want)
+        for a, b in zip(hist_s, hist_p):
+            assert abs(a[2] - b[2]) <= 1e-7 * max(a[2], 1e-12) and abs(a[3] - b[3]) <= 1e-10
+        shrinks = len({h[0] for h in hist_s})
+        dist.destroy_process_group()
+        q.put((rank, f"ok {shrinks}"))
+    except Exception:                                                    # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,n,dim,refinements,tol,min_outer", [(2, 5, 2, 2, 1e-3, 2), (4, 5, 2, 2, 1e-3, 2),
+                                                                   (2, 0, 3, 2, 1e-3, 1)])
+def test_partitioned_driver_matches_single_gpu_driver(world, n, dim, refinements, tol, min_outer):
+    """checkerboard_homogenization over several ranks (halves / quadrants about the origin), including the domain
+    shrink of a partitioned grid (n = 5: 56 -> 55 -> ...): same V-cycle counts, sigma equal to 1e-10."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_driver_worker, args=(r, world, port, n, dim, refinements, tol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in sorted(res):
+        assert msg.startswith("ok"), f"rank {rank}: {msg}"
+        assert int(msg.split()[1]) >= min_outer
