@@ -361,3 +361,34 @@ def test_unit_load_table(oracle, dim, levels):
         want = O.assemble_vector(impl.reference.levels[lev - 1])
         got = g.table_f64("load", lev)[g.table_i32("hier2slot", lev)]
         np.testing.assert_allclose(got, want, rtol=1e-13)
+
+
+def test_partitioned_shrink_host_tables(oracle):
+    """hmg_grid_shrink on a partitioned grid (host tables only): the ranks' cells are exactly the prefix, every
+    rank keeps a prefix of its own cells, and the Dirichlet masks are those of the SHRUNK global mesh."""
+    from homogenization_jl_amd import driver, dist as hdist
+    O = oracle
+    world, dim, width = 4, 2, 8
+    origin = (-width / 2.0,) * dim
+    base = driver.order_nodes_and_elements_by_magnitude(driver.hypercube(hmg.Tri64, width, origin=origin))
+    owner = hdist.block_owner(base, hdist.block_shape(world, dim), width / 2.0, origin)
+    ne_keep = driver.find_elements_in_radius(base, 3)
+    nn_keep = driver.find_nodes_in_radius(base, 3)
+    assert 0 < ne_keep < base.elements.shape[0]
+    small = O.Mesh(base.nodes[:nn_keep], base.elements[:ne_keep] - 1)
+    cn, ce, cf = O.list_boundary_nodes_edges_faces(small)
+    nedge = 3
+    want = np.zeros(ne_keep, dtype=np.int64)                     # 2D: edges are the "faces" of the mask layout
+    np.bitwise_or.at(want, ce.element, 1 << ce.local_id)
+    np.bitwise_or.at(want, cn.element, 1 << (nedge + cn.local_id))
+    seen = []
+    for rank in range(world):
+        g = hdist.PartitionedGrid(None, base, 3, owner, rank, world)
+        before = g.local_cells.copy()
+        g.shrink(ne_keep, nn_keep)
+        after = g.local_cells
+        np.testing.assert_array_equal(after, before[before < ne_keep])          # a prefix of the rank's own cells
+        assert g.ncells() == after.size
+        np.testing.assert_array_equal(g.table_i32("dmask"), want[after])
+        seen.append(after)
+    np.testing.assert_array_equal(np.sort(np.concatenate(seen)), np.arange(ne_keep))
