@@ -74,6 +74,8 @@ SIGNATURES = {
     "hmg_coarse_solve": (c_int, [vp, vp, vp]),
     "hmg_coarse_last_iterations": (c_int, [vp]),
     "hmg_vcycle": (c_int, [vp, c_int, c_int, c_int, pp]),
+    "hmg_vcycle_down": (c_int, [vp, c_int, c_int, pp]),
+    "hmg_vcycle_up": (c_int, [vp, c_int, c_int, pp]),
     "hmg_grid_set_cut": (c_int, [vp, c_i64, c_i64, c_i64, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32, c_i64, p_i64, p_i32]),
     "hmg_grid_set_exchange": (c_int, [vp, EXCHANGE_FN, EXCHANGE_FN, vp, vp, c_i64]),
     "hmg_grid_cut_buffer_doubles": (c_i64, [vp, c_int]),

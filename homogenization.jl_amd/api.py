@@ -429,8 +429,28 @@ def vcycle(implicit: ImplicitFineGrid, base: BaseLevel, ops, levels, k: int, ste
     """vcycle!(implicit, base, ops, levels, k, steps).  steps_coarse = 2 reproduces the reference,
     which does not forward `steps` to the recursive call (src/multigrid.jl:109)."""
     ops[k - 1]._bind()
+    L.check(L.load().hmg_vcycle(implicit.h, k, steps, steps_coarse, _state_handles(levels)))
+
+
+def _state_handles(levels):
     arr = (ctypes.c_void_p * (5 * len(levels)))()
     for i, st in enumerate(levels):
+        if st is None:
+            continue
         for q, h in enumerate(st.handles()):
             arr[5 * i + q] = h
-    L.check(L.load().hmg_vcycle(implicit.h, k, steps, steps_coarse, arr))
+    return arr
+
+
+def vcycle_down(implicit: ImplicitFineGrid, ops, levels, k: int, steps: int = 2):
+    """First half of one level of vcycle! (src/multigrid.jl:100-106): smoothing_steps!, local_residual!,
+    restrict_to!(next.b, P, curr.r), fill!(next.x, 0).  Only levels[k-1] and levels[k-2] are touched (other entries
+    may be None); p and Ap of level k are scratch afterwards."""
+    ops[k - 1]._bind()
+    L.check(L.load().hmg_vcycle_down(implicit.h, k, steps, _state_handles(levels)))
+
+
+def vcycle_up(implicit: ImplicitFineGrid, ops, levels, k: int, steps: int = 2):
+    """Second half (src/multigrid.jl:112-115): interpolate_and_sum_to!(curr.x, P, next.x), smoothing_steps!."""
+    ops[k - 1]._bind()
+    L.check(L.load().hmg_vcycle_up(implicit.h, k, steps, _state_handles(levels)))

@@ -915,14 +915,13 @@ void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
     launch_scatter_base(L, g->md, lv.ld, g->c_u.p, x1->d);
 }
 
-void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
+// Down leg of one level of the V-cycle (src/multigrid.jl:100-106): pre-smoother, local residual, restriction,
+// zero initial guess on the coarser level.  Inside the library the pre-smoother's dead tail is dropped and its pending
+// x-update(s) ride in the load phase of the local residual (see smooth()); x, the local residual in r and the
+// coarse right-hand side are what the reference leaves, p and Ap are scratch.
+void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st)
 {
-    // ref: src/multigrid.jl:73-119
     hmg_vec **cur = st + 5 * (k - 1);
-    if (k == 1) {
-        coarse_solve(g, cur[1], cur[0]);
-        return;
-    }
     hmg_vec **nxt = st + 5 * (k - 2);
     const Launch &L = g->ctx->L;
     // (an odd number of pointer exchanges would leave r and p swapped: both smoother calls take the same `steps`)
@@ -960,13 +959,34 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
     }
     restrict_level(g, k, cur[2]->d, nxt[1]->d);
     launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
-    vcycle(g, k - 1, steps_coarse, steps_coarse, st);
+}
+
+// Up leg (src/multigrid.jl:112-115): coarse-grid correction x_k += P x_{k-1}, post-smoother.
+void vcycle_up(hmg_grid *g, int k, int steps, hmg_vec **st)
+{
+    hmg_vec **cur = st + 5 * (k - 1);
+    hmg_vec **nxt = st + 5 * (k - 2);
+    const Launch &L = g->ctx->L;
+    const bool swap_rp = g->ctx->swap_rp && g->fuse_cg && steps > 0;
     // coarse-grid correction: folded into the post-smoother's first residual where the fused kernel can hold the
     // coarse column in LDS next to the lattice image (two workgroups per CU must still fit), else a separate pass
     const bool fold_p = g->ctx->fold_prolong && g->fuse_cg && apply_lds_bytes(lev(g, k)) <= 160 * 1024 &&
                         apply_lds_bytes(lev(g, k)) + sizeof(double) * (size_t)lev(g, k - 1).nf <= 80 * 1024;
     if (!fold_p) launch_prolong_add(L, lev(g, k), lev(g, k - 1), g->md.ncells, nxt[0]->d, cur[0]->d);
     smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], true, false, swap_rp, fold_p ? nxt[0] : nullptr);
+}
+
+void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
+{
+    // ref: src/multigrid.jl:73-119
+    if (k == 1) {
+        hmg_vec **cur = st;
+        coarse_solve(g, cur[1], cur[0]);
+        return;
+    }
+    vcycle_down(g, k, steps, st);
+    vcycle(g, k - 1, steps_coarse, steps_coarse, st);
+    vcycle_up(g, k, steps, st);
 }
 
 // ---- multi-GPU cut exchange -------------------------------------------------------------------
@@ -1866,6 +1886,30 @@ int hmg_vcycle(hmg_grid *g, int top_level, int steps, int steps_coarse, hmg_vec 
     for (int l = 1; l <= top_level; ++l)
         for (int q = 0; q < 5; ++q) check_vec(g, l, states[5 * (l - 1) + q], "states[]");
     vcycle(g, top_level, steps, steps_coarse, states);
+    HMG_END
+}
+
+static void check_two_levels(hmg_grid *g, int level, hmg_vec **states)
+{
+    need(g && g->has_op && states, "null argument or operator not set");
+    need(level >= 2 && level <= g->nlevels, "level out of range (2..nlevels)");
+    for (int l = level - 1; l <= level; ++l)
+        for (int q = 0; q < 5; ++q) check_vec(g, l, states[5 * (l - 1) + q], "states[]");
+}
+
+int hmg_vcycle_down(hmg_grid *g, int level, int steps, hmg_vec **states)
+{
+    HMG_TRY
+    check_two_levels(g, level, states);
+    vcycle_down(g, level, steps, states);
+    HMG_END
+}
+
+int hmg_vcycle_up(hmg_grid *g, int level, int steps, hmg_vec **states)
+{
+    HMG_TRY
+    check_two_levels(g, level, states);
+    vcycle_up(g, level, steps, states);
     HMG_END
 }
 

@@ -146,6 +146,15 @@ int hmg_coarse_last_iterations(const hmg_grid *grid);
  * does not forward `steps`, src/multigrid.jl:109, so pass 2 for parity).
  * states: 5*nlevels handles ordered level-major as x,b,r,p,Ap of level 1, then level 2, ... */
 int hmg_vcycle(hmg_grid *grid, int top_level, int steps, int steps_coarse, hmg_vec **states);
+/* The two halves of one level of vcycle! (same `states` layout; only levels `level` and `level - 1` are touched):
+ *   down  smoothing_steps!, local_residual!, restrict_to!(next.b, P, curr.r), fill!(next.x, 0)   (src/multigrid.jl:100-106)
+ *   up    interpolate_and_sum_to!(curr.x, P, next.x), smoothing_steps!                          (src/multigrid.jl:112-115)
+ * hmg_vcycle(k) == down(k); hmg_vcycle(k-1); up(k).  After `down`, x, r (the cell-local residual) and the coarse b
+ * hold what the reference leaves; p and Ap are scratch (the library drops the pre-smoother's dead tail).  With
+ * option "swap_rp" each half exchanges the device pointers of the r and p handles once: call them in pairs when
+ * r / p wrap caller-owned memory. */
+int hmg_vcycle_down(hmg_grid *grid, int level, int steps, hmg_vec **states);
+int hmg_vcycle_up(hmg_grid *grid, int level, int steps, hmg_vec **states);
 
 /* ---- multi-GPU hooks (one process per GPU; the host layer owns the communicator) ------------------
  * The grid of a rank holds the cells that rank owns.  Entities shared with other ranks are listed by

@@ -29,7 +29,8 @@ def relerr(a, b):
 class Case:
     """A small configuration shared by oracle and device."""
 
-    def __init__(self, O, ctx, dim, n, levels, lam=0.7, perturb=0.0, seed=0, ordered=True, mesh=None):
+    def __init__(self, O, ctx, dim, n, levels, lam=0.7, perturb=0.0, seed=0, ordered=True, mesh=None,
+                 values=(1.0, 9.0)):
         self.O, self.dim, self.levels, self.lam = O, dim, levels, lam
         m = mesh if mesh is not None else O.hypercube(dim, n, origin=(-n / 2.0,) * dim)
         if ordered and mesh is None:
@@ -38,7 +39,7 @@ class Case:
         if perturb:
             m.nodes = m.nodes + perturb * (rng.random(m.nodes.shape) - 0.5)
         self.mesh = m
-        self.sig = rng.choice([1.0, 9.0], size=(m.nelements(), dim))
+        self.sig = rng.choice(list(values), size=(m.nelements(), dim))
         self.impl = O.ImplicitFineGrid.create(m, levels)
         self.cons = O.ZeroDirichletConstraint(*O.list_boundary_nodes_edges_faces(m))
         self.ops = [O.L2PlusDivAGrad(O.build_local_diffusion_operators(l), O.mass_matrix(l), self.cons, lam, self.sig)

@@ -1,0 +1,249 @@
+"""
+GPU parity tests aimed at the instantiations the benchmark actually runs (BASELINE configs 3 and 5):
+
+  * 3D level 6 (Nf = 6545, the 1024-thread k_apply<3,1024,7,*>), directly against the oracle: apply for every
+    workgroup size, residual + constraint, the slab restriction / prolongation of level 6, the fused CG smoother,
+    and the two halves of a V-cycle level (hmg_vcycle_down / hmg_vcycle_up) which contain the pieces that only
+    exist inside hmg_vcycle: the pre-smoother's dead tail, the local residual with two pending x-updates in its
+    load phase (`x3` mode) and the prolongation folded into the post-smoother's first residual;
+  * config 5: sigma in {1, 100}, level 7 (slab kernel): one V-cycle against the oracle, contraction over four
+    cycles and a bounded coarse-solver iteration count on a mesh whose level-1 system is not trivial.
+
+Tolerances as in test_gpu_parity.py: 1e-11 per primitive, 1e-10 smoother state, 1e-9 on x after a V-cycle.
+"""
+import numpy as np
+import pytest
+
+import homogenization_jl_amd as hmg
+from test_gpu_parity import Case, TOL, _oracle_state, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hmg.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def case6(oracle, ctx):
+    # 2^3 cubes x 6 tets = 48 cells, 6 levels: Nf = 6545 on the finest (the benchmark's cell), perturbed geometry,
+    # ordered by magnitude like the driver's mesh
+    return Case(oracle, ctx, 3, 2, 6, lam=0.7, perturb=0.15, seed=41)
+
+
+@pytest.mark.parametrize("threads", [0, 1024, 640, 512])
+def test_l6_apply_every_workgroup_size(case6, ctx, threads):
+    """mul! on level 6 -- ref: src/apply_local_operators.jl:85-133; threads = 0 is the benchmark's choice (1024)."""
+    c = case6
+    lev = 6
+    ctx.set_option("apply_threads", threads)
+    try:
+        x, y = c.rand(lev), c.rand(lev)
+        want = y.copy(order="F")
+        c.O.mul(-1.3, c.mesh, c.ops[lev - 1], x, want)
+        dx, dy = c.dev(lev, x), c.dev(lev, y)
+        hmg.mul(-1.3, c.g, c.A, dx, dy)
+        assert relerr(dy.to_host(), want) <= TOL
+        # out = A x without a source vector (the smoother's Ap = A p): 16 B/DOF form
+        want2 = np.zeros_like(x, order="F")
+        c.O.mul(1.0, c.mesh, c.ops[lev - 1], x, want2)
+        c.O.apply_constraint(want2, lev, c.cons, c.impl)
+        dz = hmg.DeviceMatrix(c.g, lev)
+        hmg.apply_ex(1.0, c.g, dx, None, dz, constrain=True)
+        assert relerr(dz.to_host(), want2) <= TOL
+    finally:
+        ctx.set_option("apply_threads", 0)
+
+
+def test_l6_residual_and_constraint(case6):
+    """local_residual! / apply_constraint! on level 6 -- ref: src/apply_local_operators.jl:18-27"""
+    c = case6
+    O, lev = c.O, 6
+    st = O.LevelState.create(c.mesh.nelements(), c.impl.nf(lev))
+    st.x[...] = c.rand(lev); st.b[...] = c.rand(lev)
+    O.local_residual(c.impl, c.ops[lev - 1], st, lev)
+    dst = hmg.LevelState(c.g, lev)
+    dst.x.from_host(st.x); dst.b.from_host(st.b)
+    hmg.local_residual(c.g, c.A, dst, lev)
+    got = dst.r.to_host()
+    assert relerr(got, st.r) <= TOL
+    np.testing.assert_array_equal(got == 0.0, st.r == 0.0)
+    a = c.rand(lev)
+    want = a.copy(order="F"); O.apply_constraint(want, lev, c.cons, c.impl)
+    d = c.dev(lev, a); hmg.apply_constraint(d, lev, c.g)
+    np.testing.assert_array_equal(d.to_host(), want)
+    want = a.copy(order="F"); O.broadcast_interfaces(want, c.impl, lev)
+    d = c.dev(lev, a); hmg.broadcast_interfaces(d, c.g, lev)
+    np.testing.assert_array_equal(d.to_host(), want)
+
+
+def test_l6_transfer(case6):
+    """restrict_to! (level 6 goes through the slab kernel at the even nodes) / interpolate_and_sum_to!
+    -- ref: src/interpolation.jl:52-74"""
+    c = case6
+    O = c.O
+    for lev in (6, 5):
+        P = c.impl.reference.interops[lev - 2]
+        xf, xc = c.rand(lev), c.rand(lev - 1)
+        want = xf.copy(order="F"); O.interpolate_and_sum_to(want, P, xc)
+        df, dc = c.dev(lev, xf), c.dev(lev - 1, xc)
+        hmg.interpolate_and_sum_to(df, c.g, dc)
+        np.testing.assert_array_equal(df.to_host(), want)
+        wantb = np.zeros_like(xc, order="F"); O.restrict_to(wantb, P, xf)
+        db = hmg.DeviceMatrix(c.g, lev - 1)
+        hmg.restrict_to(db, c.g, c.dev(lev, xf))
+        assert relerr(db.to_host(), wantb) <= 1e-14
+
+
+@pytest.mark.parametrize("steps", [3, 1])
+def test_l6_smoothing_steps(case6, steps):
+    """smoothing_steps! on level 6 (fused CG pass of k_apply<3,1024,7,true>) -- ref: src/multigrid.jl:46-71"""
+    c = case6
+    lev = 6
+    st = _oracle_state(c, lev)
+    dst = hmg.LevelState(c.g, lev)
+    dst.x.from_host(st.x); dst.b.from_host(st.b)
+    c.O.smoothing_steps(steps, c.impl, c.ops[lev - 1], st, lev)
+    hmg.smoothing_steps(steps, c.g, c.A, dst, lev)
+    assert relerr(dst.x.to_host(), st.x) <= 1e-10
+    assert relerr(dst.r.to_host(), st.r) <= 1e-10
+    assert relerr(dst.p.to_host(), st.p) <= 1e-10
+    assert relerr(dst.Ap.to_host(), st.Ap) <= 1e-10
+
+
+OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead")
+
+
+@pytest.mark.parametrize("plain", [0, 1])
+@pytest.mark.parametrize("steps", [3, 2, 1])
+def test_l6_vcycle_down_leg(case6, ctx, steps, plain):
+    """First half of a V-cycle level: smoothing_steps!, local_residual!, restrict_to!, fill!(next.x, 0)
+    (src/multigrid.jl:100-106).  plain = 0 is what hmg_vcycle runs: the pre-smoother's last step writes nothing and the
+    local residual applies both pending x-updates in its load phase (steps >= 2: `x3` mode; steps = 1: one pending
+    update).  x, the cell-local residual and the coarse right-hand side against the oracle, 1e-10."""
+    c = case6
+    O, lev = c.O, 6
+    st = _oracle_state(c, lev)
+    x0, b0 = st.x.copy(order="F"), st.b.copy(order="F")
+    O.smoothing_steps(steps, c.impl, c.ops[lev - 1], st, lev)
+    O.local_residual(c.impl, c.ops[lev - 1], st, lev)
+    nb = np.zeros((c.impl.nf(lev - 1), c.mesh.nelements()), order="F")
+    O.restrict_to(nb, c.impl.reference.interops[lev - 2], st.r)
+    for o in OPTS:
+        ctx.set_option(o, 0 if plain else 1)
+    try:
+        states = [None] * 6
+        states[4], states[5] = hmg.LevelState(c.g, 5), hmg.LevelState(c.g, 6)
+        states[5].x.from_host(x0); states[5].b.from_host(b0)
+        states[4].x.from_host(c.rand(5))                                # must come back as zeros
+        hmg.vcycle_down(c.g, [c.A] * 6, states, lev, steps)
+        assert relerr(states[5].x.to_host(), st.x) <= 1e-10
+        assert relerr(states[5].r.to_host(), st.r) <= 1e-10
+        assert relerr(states[4].b.to_host(), nb) <= 1e-10
+        assert not states[4].x.to_host().any()
+    finally:
+        for o in OPTS:
+            ctx.set_option(o, 1)
+
+
+@pytest.mark.parametrize("plain", [0, 1])
+def test_l6_vcycle_up_leg(case6, ctx, plain):
+    """Second half: interpolate_and_sum_to!(curr.x, P, next.x), smoothing_steps! (src/multigrid.jl:112-115).  plain = 0:
+    the prolongation rides in the load phase of the post-smoother's first residual (coarse column staged in LDS)."""
+    c = case6
+    O, lev, steps = c.O, 6, 3
+    st = _oracle_state(c, lev)
+    x0, b0 = st.x.copy(order="F"), st.b.copy(order="F")
+    xc = c.rand(lev - 1)
+    O.broadcast_interfaces(xc, c.impl, lev - 1)                          # a consistent coarse correction
+    O.apply_constraint(xc, lev - 1, c.cons, c.impl)
+    O.interpolate_and_sum_to(st.x, c.impl.reference.interops[lev - 2], xc)
+    O.smoothing_steps(steps, c.impl, c.ops[lev - 1], st, lev)
+    for o in OPTS:
+        ctx.set_option(o, 0 if plain else 1)
+    try:
+        states = [None] * 6
+        states[4], states[5] = hmg.LevelState(c.g, 5), hmg.LevelState(c.g, 6)
+        states[5].x.from_host(x0); states[5].b.from_host(b0)
+        states[4].x.from_host(xc)
+        hmg.vcycle_up(c.g, [c.A] * 6, states, lev, steps)
+        assert relerr(states[5].x.to_host(), st.x) <= 1e-10
+        assert relerr(states[5].r.to_host(), st.r) <= 1e-10
+        # (with swap_rp a single half leaves the r / p handles exchanged an odd number of times: both halves together
+        #  are what hmg_vcycle runs; the handles still name r and p)
+        assert relerr(states[5].p.to_host(), st.p) <= 1e-10
+    finally:
+        for o in OPTS:
+            ctx.set_option(o, 1)
+
+
+def test_l6_vcycle(case6):
+    """One and two full V-cycles through all six levels: x 1e-9, r / p 1e-8 -- ref: src/multigrid.jl:73-119"""
+    c = case6
+    O, lev = c.O, 6
+    sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(lev)]
+    sts[-1] = _oracle_state(c, lev)
+    dsts = [hmg.LevelState(c.g, i + 1) for i in range(lev)]
+    dsts[-1].x.from_host(sts[-1].x); dsts[-1].b.from_host(sts[-1].b)
+    base, dbase = O.make_base_level(c.mesh, c.sig, c.lam), hmg.BaseLevel(c.g)
+    for cyc in range(2):
+        O.vcycle(c.impl, base, c.ops, sts, lev, 3)
+        hmg.vcycle(c.g, dbase, [c.A] * lev, dsts, lev, 3)
+        assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9, cyc
+        assert relerr(dsts[-1].r.to_host(), sts[-1].r) <= 1e-8, cyc
+        assert relerr(dsts[-1].p.to_host(), sts[-1].p) <= 1e-8, cyc
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: high contrast, refinements = 6
+# ---------------------------------------------------------------------------------------------------------------
+def test_config5_contrast100_level7_vcycle_matches_oracle(oracle, ctx):
+    """sigma in {1, 100}, 7 levels (slab kernel, Nf = 47 905), 4^3 cubes (27 interior level-1 nodes): one V-cycle
+    against the oracle, x 1e-9 / r 1e-8."""
+    O = oracle
+    lev = 7
+    c = Case(O, ctx, 3, 4, lev, lam=1.0, seed=51, values=(1.0, 100.0))
+    assert set(np.unique(c.sig)) == {1.0, 100.0}
+    sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(lev)]
+    sts[-1] = _oracle_state(c, lev)
+    dsts = [hmg.LevelState(c.g, i + 1) for i in range(lev)]
+    dsts[-1].x.from_host(sts[-1].x); dsts[-1].b.from_host(sts[-1].b)
+    base, dbase = O.make_base_level(c.mesh, c.sig, 1.0), hmg.BaseLevel(c.g)
+    O.vcycle(c.impl, base, c.ops, sts, lev, 3)
+    hmg.vcycle(c.g, dbase, [c.A] * lev, dsts, lev, 3)
+    assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9
+    assert relerr(dsts[-1].r.to_host(), sts[-1].r) <= 1e-8
+    assert 0 < dbase.last_iterations() <= 200
+
+
+def test_config5_contrast100_convergence_and_coarse_iterations(ctx):
+    """Convergence stress of config 5 at a size whose level-1 system is not trivial (12^3 cubes: 1331 interior level-1
+    unknowns, 10 368 cells, 6 levels so that the whole state fits comfortably): four V-cycles contract the unique
+    residual norm monotonically, by at least 0.5 per cycle on average, and the level-1 Jacobi-PCG (rtol 1e-13) stays
+    within a bounded iteration count under contrast 100."""
+    from homogenization_jl_amd import driver
+    L, w = 6, 12
+    base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, w, L, seed=5, values=(1.0, 100.0))
+    states = [hmg.LevelState(g, i + 1) for i in range(L)]
+    top = states[-1]
+    top.x.rand(77)
+    hmg.broadcast_interfaces(top.x, g, L)
+    hmg.apply_constraint(top.x, L, g)
+    hmg.rhs_axi_grad_v(top.b, g, driver.random_unit_vec(3))
+    bl = hmg.BaseLevel(g)
+    norms, its = [], []
+    for _ in range(4):
+        hmg.vcycle(g, bl, [op] * L, states, L, 3)
+        norms.append(hmg.norm_unique(top.r))
+        its.append(bl.last_iterations())
+    assert all(np.isfinite(norms))
+    assert all(b < a for a, b in zip(norms, norms[1:])), norms
+    assert norms[-1] <= 0.5 ** 3 * norms[0], norms
+    assert 0 < max(its) <= 600, its
+    for s in states:
+        for v in (s.x, s.b, s.r, s.p, s.Ap):
+            v.close()
+    g.close()
