@@ -45,9 +45,15 @@ def test_device_follows_the_oracle_cycle_by_cycle(oracle):
         want, xs_o, _ = D.run_oracle(oracle)
         got, xs_d = D.run_device(hmg, ctx, oracle)
         assert BAND[0] <= _tail_ratio(got) <= BAND[1]
+        # Measured (tools/dev/docs_drift.py): norm(r) agrees to 1e-13 for the first 40 cycles, then the difference grows
+        # by ~10x per 3 cycles and saturates at 1-6 % of the (by then 1e-3 ... 1e-7) residual (it differs from run to run: the
+        # oracle's OpenMP dot products are not bit-reproducible either): the CG coefficients
+        # depend on the iterate, and the direction of the tail residual is a sensitive function of rounding (any two
+        # FP64 implementations -- e.g. another dot-product summation order -- separate the same way).  x itself
+        # stays within 3e-7 of max|x| throughout.
         for i, (a, b) in enumerate(zip(want, got)):
-            assert abs(a - b) <= 1e-7 * a, (i, a, b)                    # norm(r) per cycle
-        for i in (0, 9, 99):
-            assert np.abs(xs_d[i] - xs_o[i]).max() <= 1e-9 * np.abs(xs_o[i]).max(), i
+            assert abs(a - b) <= (1e-10 if i < 40 else 0.25) * a, (i, a, b)
+        for i in range(100):
+            assert np.abs(xs_d[i] - xs_o[i]).max() <= (1e-12 if i < 40 else 2e-6) * np.abs(xs_o[i]).max(), i
     finally:
         ctx.close()
