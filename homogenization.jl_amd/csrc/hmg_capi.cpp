@@ -64,7 +64,9 @@ struct LevelBufs {
     DevBuf<uint16_t> slab_cp_slot, slab_rs_slot;
     DevBuf<double> rtab;   // restriction weights in class-table layout (slab levels)
     int nslab = 0, slab_lds_nodes = 0;
-    DevBuf<uint32_t> pos32, pos32w, sweep32, par32;
+    DevBuf<uint32_t> pos32, pos32w, sweep32, par32, blk_word;
+    DevBuf<uint16_t> blk_slot;
+    int nblk = 0, blk_R = 0;
     DevBuf<double> ctab;
     DevBuf<int32_t> hier2slot, par_a, par_b, rptr, ridx;
     DevBuf<double> dphi;
@@ -99,7 +101,7 @@ struct hmg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf<double> partials, scal;
+    DevBuf<double> partials, scal, rpart;
     Launch L{};
     int coarse_maxit = 5000;
     int coarse_check = 25;
@@ -206,6 +208,17 @@ void check_vec(const hmg_grid *g, int level, const hmg_vec *v, const char *name)
 
 int64_t vec_len(const hmg_vec *v) { return (int64_t)v->g->ld[v->level - 1].ld * v->g->md.ncells; }
 
+// scratch of the streaming reductions (one partial per 256-thread block = per 512 entries, see hmg_kernels.hip)
+void ensure_reduce_scratch(hmg_ctx *c, int64_t nentries)
+{
+    const int64_t need_blocks = nentries / 512 + 2;
+    if (need_blocks <= 2048 || need_blocks <= c->L.rpart_cap) return;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->rpart.alloc((size_t)need_blocks);
+    c->L.rpart = c->rpart.p;
+    c->L.rpart_cap = need_blocks;
+}
+
 void upload_mesh(hmg_grid *g)
 {
     const MeshTables &M = g->cur();
@@ -302,6 +315,59 @@ static void upload_levels(hmg_grid *g)
                 B.pos32.upload(p32, s);
                 B.pos32w.upload(p32w, s);
                 B.sweep32.upload(s32, s);
+            }
+            // register-blocked interior of k_apply (interior_block in hmg_kernels.hip): every R-th interior k-plane,
+            // all its interior (i,j) in lattice order; R = 6 makes the 4495 interior nodes of level 6 945 entries,
+            // one pass of a 1024-thread workgroup
+            if (T.dim == 3 && T.nint > 0 && T.m <= 63 && T.nf > 2048 && sizeof(double) * (size_t)(T.nf + 512) <= 160 * 1024) {
+                const int R = 6, m = T.m;
+                std::vector<int32_t> slot_of_L(T.nf, -1);
+                for (int q = 0; q < T.nf; ++q) slot_of_L[(size_t)(T.meta[q] & 0xffffu)] = q;
+                auto tri = [](int n) { return (n + 1) * (n + 2) / 2; };
+                std::vector<int> PO(m + 2, 0);
+                for (int k = 0; k <= m; ++k) PO[k + 1] = PO[k] + tri(m - k);
+                auto lin = [&](int i, int j, int k) { return PO[k] + j * (m - k + 1) - j * (j - 1) / 2 + i; };
+                std::vector<uint32_t> bw;
+                std::vector<uint16_t> bs;
+                size_t covered = 0;
+                for (int k0 = 1; k0 <= m - 3; k0 += R)
+                    for (int j = 1; j + k0 <= m - 2; ++j)
+                        for (int i = 1; i + j + k0 <= m - 1; ++i) {
+                            const int nv = std::min(R, m - i - j - k0);
+                            const int L = lin(i, j, k0), sl = slot_of_L[L];
+                            if (sl < T.off_int || T.slot_cls[sl] != 0) throw std::runtime_error("blocked interior: not an interior node");
+                            // the kernel derives the slots of the R nodes from the first: check that rule here
+                            int ds = tri(m - k0 - 3) - (j - 1), cur = sl;
+                            for (int r = 1; r < nv; ++r) {
+                                cur += ds;
+                                ds -= (m - k0) - 1 - r;
+                                if (cur != slot_of_L[lin(i, j, k0 + r)]) throw std::runtime_error("blocked interior: slot rule broken");
+                            }
+                            bw.push_back((uint32_t)L | ((uint32_t)j << 16) | ((uint32_t)k0 << 22) | ((uint32_t)nv << 28));
+                            bs.push_back((uint16_t)sl);
+                            covered += nv;
+                        }
+                if ((int)covered != T.nint) throw std::runtime_error("blocked interior: tables do not cover the interior");
+                // the same instantiation evaluates the faces one class per wave and skips the taps that leave the cell
+                // (face_tap_mask in hmg_kernels.hip: f0 k = 0, f1 j = 0, f2 i = 0, f3 i+j+k = m): check them against
+                // the class table, and the run counts the kernel is compiled for (4 waves x 2 runs of 64 per face,
+                // 3 runs of 64 for corners + edges)
+                static const uint32_t absent[4] = {1u << 8 | 1u << 10 | 1u << 12 | 1u << 14, 1u << 4 | 1u << 6 | 1u << 7 | 1u << 13,
+                                                   1u << 2 | 1u << 3 | 1u << 9 | 1u << 14, 1u << 1 | 1u << 5 | 1u << 11 | 1u << 13};
+                bool ok = T.nface == 4 && T.nfi <= 512 && T.off_face <= 192 && (int)bw.size() <= 15 * 64;
+                for (int f = 0; ok && f < 4; ++f)
+                    for (int d = 0; d < T.ndir; ++d) {
+                        bool zero = true;
+                        for (int t = 0; t < T.nterm; ++t) zero = zero && T.ctab[((size_t)(1 + f) * T.ndir + d) * T.nterm + t] == 0.0;
+                        if (((absent[f] >> d) & 1u) && !zero) ok = false;   // a tap the kernel skips carries weight
+                    }
+                if (!ok) throw std::runtime_error("blocked apply: the class table does not match the kernel's face tap masks");
+                B.nblk = (int)bw.size();
+                B.blk_R = R;
+                bw.resize(bw.size() + TABLE_PAD, 0u);
+                bs.resize(bs.size() + TABLE_PAD, (uint16_t)0);
+                B.blk_word.upload(bw, s);
+                B.blk_slot.upload(bs, s);
             }
             // slab tables: needed by the apply of levels whose cell exceeds the LDS (level 7), and used by the
             // restriction of every large 3D level (level 6: the whole cell is one slab)
@@ -479,6 +545,10 @@ static void upload_levels(hmg_grid *g)
         D.pos32w = B.pos32w.p;
         D.sweep32 = B.sweep32.p;
         D.nsweep = (int)T.sweep_meta.size();
+        D.blk_word = B.blk_word.p;
+        D.blk_slot = B.blk_slot.p;
+        D.nblk = B.nblk;
+        D.blk_R = B.blk_R;
         D.ctab = B.ctab.p;
         D.hier2slot = B.hier2slot.p;
         D.par_a = B.par_a.p;
@@ -1073,10 +1143,13 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     HIPCHK(hipMemsetAsync(c->scal.p, 0, S_COUNT * sizeof(double), c->stream));
     c->L.stream = c->stream;
     c->L.partials = c->partials.p;
+    c->L.rpart = nullptr;
+    c->L.rpart_cap = 0;
     c->L.scal = c->scal.p;
     c->L.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->L.apply_threads = 0;
     c->L.apply_mass_only = 0;
+    c->L.apply_unblocked = 0;
     *out = c.release();
     HMG_END
 }
@@ -1112,6 +1185,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
     if (n == "apply_threads")
         ctx->L.apply_threads = (int)value;
 
+    else if (n == "apply_unblocked")
+        ctx->L.apply_unblocked = value != 0;
     else if (n == "coarse_maxit")
         ctx->coarse_maxit = (int)value;
     else if (n == "coarse_check")
@@ -1466,6 +1541,7 @@ int hmg_vec_create(hmg_grid *g, int level, hmg_vec **out)
     v->own = true;
     v->alloc_cells = g->md.ncells;
     size_t bytes = sizeof(double) * (size_t)lv.ld * (size_t)g->md.ncells;
+    ensure_reduce_scratch(g->ctx, (int64_t)lv.ld * g->md.ncells);
     HIPCHK(hipMalloc((void **)&v->d, bytes));
     HIPCHK(hipMemsetAsync(v->d, 0, bytes, g->ctx->stream));
     *out = v.release();
@@ -1476,7 +1552,7 @@ int hmg_vec_wrap(hmg_grid *g, int level, void *device_ptr, hmg_vec **out)
 {
     HMG_TRY
     need(g && out && device_ptr, "null argument");
-    (void)lev(g, level);
+    ensure_reduce_scratch(g->ctx, (int64_t)lev(g, level).ld * g->md.ncells);
     std::unique_ptr<hmg_vec> v(new hmg_vec);
     v->g = g;
     v->level = level;

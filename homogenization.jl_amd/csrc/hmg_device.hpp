@@ -27,6 +27,10 @@ struct LevelDev {
     const uint32_t *pos32;         // [nf + TABLE_PAD] L | j<<16 | k<<22 | cls<<28 (levels whose cell fits the LDS)
     const uint32_t *pos32w;        // [nf]     i | j<<7 | k<<14 | cls<<21  (3D, any level)
     const uint32_t *sweep32;       // [nsweep + TABLE_PAD] same packing, cls = 0
+    // register-blocked interior (3D, see interior_block): one entry per interior (i,j) of every blk_R-th k-plane
+    const uint32_t *blk_word;      // [nblk + TABLE_PAD] L | j<<16 | k0<<22 | nv<<28
+    const uint16_t *blk_slot;      // [nblk + TABLE_PAD] storage slot of node (i,j,k0)
+    int nblk, blk_R;               // blk_R = 0: no blocked tables for this level
     const double *ctab;            // [ncls*ndir*nterm]
     const int32_t *hier2slot;      // [nf]
     const int32_t *par_a, *par_b;  // [nf]     (level > 1)
@@ -103,10 +107,13 @@ enum { S_RS = 0, S_PAP = 1, S_RS2 = 2, S_TMP = 3, S_C0 = 4, S_C1 = 5, S_C2 = 6, 
 struct Launch {
     hipStream_t stream;
     double *partials;     // >= 4096 doubles
+    double *rpart;        // block partials of the streaming reductions: one per 512 vector entries
+    int64_t rpart_cap;
     double *scal;         // S_COUNT doubles
     int num_cu;
     int apply_threads;    // 0 = auto
     int apply_mass_only;  // 1: only the mass term (next_rhs!), set around a single launch
+    int apply_unblocked;  // 1: node-per-thread interior sweep instead of the register-blocked one (dev / A-B knob)
 };
 
 // out = (src ? src : 0) + alpha * A x, then (use_mask) zero Dirichlet DOFs.  src may alias out.

@@ -200,6 +200,167 @@ __device__ __forceinline__ void decode32w(uint32_t w, int m, int &L, int &len, i
     L = (full - rest) / 6 + j * (n + 1) - ((j * (j - 1)) >> 1) + i;
 }
 
+// Stencil taps that leave the cell at a node in the interior of face F (F = 0: k = 0, 1: j = 0, 2: i = 0, 3: i+j+k = m;
+// tap numbering of stencil_eval_v): their class weights are zero, the host checks that against the class table.
+__host__ __device__ constexpr uint32_t face_tap_mask(int f)
+{
+    return 0x7fffu & ~(f == 0   ? (1u << 8 | 1u << 10 | 1u << 12 | 1u << 14)
+                       : f == 1 ? (1u << 4 | 1u << 6 | 1u << 7 | 1u << 13)
+                       : f == 2 ? (1u << 2 | 1u << 3 | 1u << 9 | 1u << 14)
+                                : (1u << 1 | 1u << 5 | 1u << 11 | 1u << 13));
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const unsigned lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const unsigned hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// Face-interior nodes, one entity class per wave: the class weight row sits in SGPRs (one LDS read + readlanes per
+// wave instead of 15 LDS reads per node) and only the 11 taps that exist are read -- 11 LDS reads per node instead
+// of 30.  A wave evaluates up to NITEM runs of 64 consecutive slots of face F; fw[] holds their addressing words.
+template <int F, int NITEM, bool FUSED>
+__device__ __forceinline__ void face_items(const double *W, const double *xs, int m, int nfi, int slot_base, int t0,
+                                           const uint32_t (&fw)[NITEM], bool dirichlet, double mult, const double *sc,
+                                           double *oc, double &pap, int lane)
+{
+    constexpr uint32_t M = face_tap_mask(F);
+    const double wv = lds_ld(W + (1 + F) * 15 + (lane < 15 ? lane : 0));
+    double w[15];
+#pragma unroll
+    for (int d = 0; d < 15; ++d) w[d] = (M >> d) & 1u ? readlane_f64(wv, d) : 0.0;
+#pragma unroll
+    for (int q = 0; q < NITEM; ++q) {
+        const int ti = t0 + q * 64 + lane;
+        if (ti < nfi) {
+            const int t = slot_base + ti;
+            double o = 0.0;
+            if (!dirichlet) {
+                const double sv = sc ? sc[t] : 0.0;
+                int L, len, A, B, cls;
+                decode32<3>(fw[q], m, L, len, A, B, cls);
+                const double *p = xs + L;
+                const double ctr = lds_ld(p);
+                double acc = w[0] * ctr;
+                if ((M >> 1) & 1u) acc += w[1] * lds_ld(p + 1);
+                if ((M >> 2) & 1u) acc += w[2] * lds_ld(p - 1);
+                if ((M >> 3) & 1u) acc += w[3] * lds_ld(p + len - 1);
+                if ((M >> 4) & 1u) acc += w[4] * lds_ld(p - len);
+                if ((M >> 5) & 1u) acc += w[5] * lds_ld(p + len);
+                if ((M >> 6) & 1u) acc += w[6] * lds_ld(p - len - 1);
+                const double *pu = p + A, *pd = p - B;
+                if ((M >> 7) & 1u) acc += w[7] * lds_ld(pu - len);
+                if ((M >> 8) & 1u) acc += w[8] * lds_ld(pd + len + 1);
+                if ((M >> 9) & 1u) acc += w[9] * lds_ld(pu - 1);
+                if ((M >> 10) & 1u) acc += w[10] * lds_ld(pd + 1);
+                if ((M >> 11) & 1u) acc += w[11] * lds_ld(pu);
+                if ((M >> 12) & 1u) acc += w[12] * lds_ld(pd);
+                if ((M >> 13) & 1u) acc += w[13] * lds_ld(pu + 1 - len);
+                if ((M >> 14) & 1u) acc += w[14] * lds_ld(pd + len);
+                o = sv + acc;
+                if (FUSED) pap += mult * (ctr * o);
+            }
+            if (!FUSED || oc) oc[t] = o;
+        }
+    }
+}
+
+// Register-blocked evaluation of the cell interior (3D).  A thread owns R nodes (i, j, k0 .. k0+R-1) -- the same (i,j)
+// in R consecutive k-planes -- and walks the planes k0-1 .. k0+R once: in every plane it reads the 7 lattice points
+// (i,j-1) (i+1,j-1) | (i-1,j) (i,j) (i+1,j) | (i-1,j+1) (i,j+1) and feeds each value to every node of the thread
+// that taps it (the node in that plane takes all 7, the node below the first 4, the node above the last 4):
+// 7R + 14 LDS reads for R nodes instead of 15R, one addressing word per R nodes, R independent FMA chains.  Lanes
+// enumerate the interior (i,j) of plane k0 in lattice order, so a wave reads (nearly) consecutive LDS words.
+// Block word: L(i,j,k0) | j << 16 | k0 << 22 | nv << 28, nv = number of the R nodes that exist (i+j+k <= m-1);
+// blk_slot: storage slot of node (i,j,k0).  Planes that only non-existent nodes would tap are read at a safe
+// address in the middle of the image (values unused).
+template <int R, bool FUSED, bool SRC>
+__device__ __forceinline__ void interior_block(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
+                                               int slot0, const double *sc, double *oc, double &pap)
+{
+    const int L = (int)(word & 0xffffu), j = (int)((word >> 16) & 63u), k0 = (int)((word >> 22) & 63u);
+    const int nv = (int)(word >> 28);
+    const int n0 = m - k0;
+    // storage slots of the R nodes: the cell interior is itself a lattice (m' = m - 4) stored in lattice order,
+    // slot(r+1) - slot(r) = T(n0 - 3 - r) - (j - 1)
+    const int ds0 = (int)(__umul24((uint32_t)(n0 - 2), (uint32_t)(n0 - 1)) >> 1) - j + 1;
+    double acc[R];
+    if (SRC) {   // out = src + alpha A x: the sum starts from src (issued first: the global latency hides behind the planes)
+        int sl = slot0, ds = ds0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r] = r < nv ? sc[sl] : 0.0;
+            sl += ds;
+            ds -= n0 - 2 - r;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    }
+    double ctr[R];
+    int len = n0 + 2 - j;                                                                  // row j of plane k0-1
+    int delta = (int)(__umul24((uint32_t)(n0 + 2), (uint32_t)(n0 + 3)) >> 1) - j;         // q(k0) - q(k0-1) = T(n0+1) - j
+    int q = L - delta;
+    int slot = slot0, ds = ds0;
+#pragma unroll
+    for (int s = 0; s < R + 2; ++s) {
+        const int qs = s <= nv + 1 ? q : safe;
+        const double *a1 = xs + (qs - len - 1), *a2 = xs + (qs - 1), *a3 = xs + (qs + len - 1);
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3, v4 = 0.0, v5 = 0.0, v6 = 0.0;
+        if (s >= 1) {
+            v0 = lds_ld(a1);
+            v1 = lds_ld(a1 + 1);
+            v2 = lds_ld(a2);
+        }
+        v3 = lds_ld(a2 + 1);
+        if (s <= R) {
+            v4 = lds_ld(a2 + 2);
+            v5 = lds_ld(a3);
+            v6 = lds_ld(a3 + 1);
+        }
+        if (s >= 2) {                       // upper plane of node s-2: its last taps, then it is done
+            double t = acc[s - 2];
+            t += w[7] * v0;
+            t += w[13] * v1;
+            t += w[9] * v2;
+            t += w[11] * v3;
+            if (s - 2 < nv) {
+                if (!FUSED || oc) oc[slot] = t;
+                if (FUSED) pap += ctr[s - 2] * t;   // (meaningful for the CG passes, which have no src)
+            }
+            slot += ds;
+            ds -= n0 - s;                   // n0 - 2 - r, r = s - 2
+        }
+        if (s >= 1 && s <= R) {             // the plane of node s-1
+            double t = acc[s - 1];
+            ctr[s - 1] = v3;
+            t += w[0] * v3;
+            t += w[1] * v4;
+            t += w[2] * v2;
+            t += w[3] * v5;
+            t += w[4] * v1;
+            t += w[5] * v6;
+            t += w[6] * v0;
+            acc[s - 1] = t;
+        }
+        if (s < R) {                        // lower plane of node s
+            double t = acc[s];
+            t += w[12] * v3;
+            t += w[10] * v4;
+            t += w[14] * v5;
+            t += w[8] * v6;
+            acc[s] = t;
+        }
+        q += delta;
+        delta -= n0 + 2 - s;               // T(n) - T(n-1) = n + 1, n = n0 + 1 - s
+        len -= 1;
+        // (scheduling fence: without it the backend hoists the LDS reads of several planes above the FMAs of the
+        //  first and spills; one plane's 7 values + 3 running sums is what has to be live -- 64-VGPR budget)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // One workgroup per coarse cell.  Load phase: coalesced column read, scatter into the LDS lattice
 // image through the u16 position table.  Compute phase: surface slots (entity-major storage, class
 // uniform per run) take their weight row from the LDS class table; the cell interior is swept in
@@ -217,7 +378,7 @@ __device__ __forceinline__ void decode32w(uint32_t w, int m, int &L, int &len, i
 #define HMG_STAMP(i)
 #endif
 
-template <int DIM, int NT, int SPT, bool FUSED>
+template <int DIM, int NT, int SPT, bool FUSED, int RB>
 __global__ void __launch_bounds__(NT, NT >= 640 ? 8 : 1)   // 2 x 1024 / 3 x 640 threads per CU need <= 64 VGPRs
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
@@ -354,13 +515,34 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const int nsurf = lv.off_int;
     // (pos32 / sweep32 / sweep_slot carry TABLE_PAD entries of padding -- zero words, slot 0xffff -- so the
     //  two-ahead prefetch needs no bounds checks and both loops have a wave-uniform trip count)
-    uint32_t p0 = lv.pos32[tid];
-    uint32_t p1 = lv.pos32[tid + NT];
-    const int nsw = lv.nsweep;
-    uint32_t q0 = lv.sweep32[tid];
-    uint32_t q1 = lv.sweep32[tid + NT];
-    int s0 = (int)lv.sweep_slot[tid];
-    int s1 = (int)lv.sweep_slot[tid + NT];
+    // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the last wave takes the
+    // corners and edges (EI runs) instead of an interior block -- the 945 blocks of level 6 fill waves 0..14.
+    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, FI = 2, EI = 3;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int face = wave / WPF, ft0 = (wave % WPF) * (FI * 64);
+    uint32_t fw[FI] = {0u, 0u}, ew[EI] = {0u, 0u, 0u};
+    uint32_t p0 = 0u, p1 = 0u;
+    if (RB) {
+#pragma unroll
+        for (int q = 0; q < FI; ++q) {
+            const int ti = ft0 + q * 64 + lane;
+            if (ti < lv.nfi) fw[q] = lv.pos32[lv.off_face + face * lv.nfi + ti];
+        }
+        if (wave == NW - 1) {
+#pragma unroll
+            for (int q = 0; q < EI; ++q) ew[q] = lv.pos32[q * 64 + lane];     // (table is padded)
+        }
+    } else {
+        p0 = lv.pos32[tid];
+        p1 = lv.pos32[tid + NT];
+    }
+    const int nsw = RB ? lv.nblk : lv.nsweep;
+    const uint32_t *iw = RB ? lv.blk_word : lv.sweep32;
+    const uint16_t *is = RB ? lv.blk_slot : lv.sweep_slot;
+    uint32_t q0 = iw[tid];
+    uint32_t q1 = RB ? 0u : iw[tid + NT];
+    int s0 = (int)is[tid];
+    int s1 = RB ? 0 : (int)is[tid + NT];
     uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
     if (FUSED) {
         const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
@@ -372,50 +554,85 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     HMG_STAMP(3);
 
     // surface entities
-    const int nit_surf = (nsurf + NT - 1) / NT;
-    for (int it = 0; it < nit_surf; ++it) {
-        const int t = tid + it * NT;
-        const uint32_t pw = p0;
-        p0 = p1;
-        p1 = lv.pos32[t + 2 * NT];
-        if (t < nsurf) {
-            const double sv = sc ? sc[t] : 0.0;
-            int L, len, A, B, cls;
-            decode32<DIM>(pw, m, L, len, A, B, cls);
-            double ctr;
-            double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
-            if ((dm >> (cls - 1)) & 1u) o = 0.0;
-            if (!FUSED || oc) oc[t] = o;
-            if (FUSED) {
-                const int e = cls - 1;
-                const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
-                const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
-                pap += (double)mu * (ctr * o);
+    auto surface_node = [&](int t, uint32_t pw) {      // any class: weight row read from the LDS class table tap by tap
+        const double sv = sc ? sc[t] : 0.0;
+        int L, len, A, B, cls;
+        decode32<DIM>(pw, m, L, len, A, B, cls);
+        double ctr;
+        double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+        if ((dm >> (cls - 1)) & 1u) o = 0.0;
+        if (!FUSED || oc) oc[t] = o;
+        if (FUSED) {
+            const int e = cls - 1;
+            const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
+            const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
+            pap += (double)mu * (ctr * o);
+        }
+    };
+    if (RB) {
+        if (DIM == 3) {
+            const bool fdir = (dm >> face) & 1u;
+            const double fmult = (double)((mq[0] >> (8 * face)) & 0xffu);
+            const int fbase = lv.off_face + face * lv.nfi;
+            if (face == 0)
+                face_items<0, FI, FUSED>(W, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane);
+            else if (face == 1)
+                face_items<1, FI, FUSED>(W, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane);
+            else if (face == 2)
+                face_items<2, FI, FUSED>(W, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane);
+            else
+                face_items<3, FI, FUSED>(W, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane);
+            if (wave == NW - 1) {
+#pragma unroll
+                for (int q = 0; q < EI; ++q) {
+                    const int t = q * 64 + lane;
+                    if (t < lv.off_face) surface_node(t, ew[q]);
+                }
             }
+        }
+    } else {
+        const int nit_surf = (nsurf + NT - 1) / NT;
+        for (int it = 0; it < nit_surf; ++it) {
+            const int t = tid + it * NT;
+            const uint32_t pw = p0;
+            p0 = p1;
+            p1 = lv.pos32[t + 2 * NT];
+            if (t < nsurf) surface_node(t, pw);
         }
     }
     HMG_STAMP(4);
     // cell interior: one weight row for all nodes
-    double w0[NDIR];
+    double w0[15];
 #pragma unroll
     for (int d = 0; d < NDIR; ++d) w0[d] = to_sgpr(W[d]);
-    const int nit_sweep = (nsw + NT - 1) / NT;
-    for (int it = 0; it < nit_sweep; ++it) {
-        const int u = tid + it * NT;
-        const uint32_t pw = q0;
-        const int t = s0;
-        q0 = q1;
-        s0 = s1;
-        q1 = lv.sweep32[u + 2 * NT];
-        s1 = (int)lv.sweep_slot[u + 2 * NT];
-        if (t != 0xffff) {
-            const double sv = sc ? sc[t] : 0.0;
-            int L, len, A, B, cls;
-            decode32<DIM>(pw, m, L, len, A, B, cls);
-            double ctr;
-            const double o = sv + stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
-            if (!FUSED || oc) oc[t] = o;
-            if (FUSED) pap += ctr * o;
+    if (RB) {
+        // register-blocked interior: one pass (the host selects this instantiation only if nblk <= NT), its word
+        // was fetched before the barrier
+        if (DIM == 3 && tid < nsw) {
+            if (sc)
+                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap);
+            else
+                interior_block<RB ? RB : 1, FUSED, false>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap);
+        }
+    } else {
+        const int nit_sweep = (nsw + NT - 1) / NT;
+        for (int it = 0; it < nit_sweep; ++it) {
+            const int u = tid + it * NT;
+            const uint32_t pw = q0;
+            const int t = s0;
+            q0 = q1;
+            s0 = s1;
+            q1 = iw[u + 2 * NT];
+            s1 = (int)is[u + 2 * NT];
+            if (t != 0xffff) {
+                const double sv = sc ? sc[t] : 0.0;
+                int L, len, A, B, cls;
+                decode32<DIM>(pw, m, L, len, A, B, cls);
+                double ctr;
+                const double o = sv + stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
+                if (!FUSED || oc) oc[t] = o;
+                if (FUSED) pap += ctr * o;
+            }
         }
     }
     HMG_STAMP(5);
@@ -647,10 +864,10 @@ size_t apply_lds_bytes(const LevelDev &lv)
     return sizeof(double) * (size_t)(WSZ + lv.lds_g0 + lv.nf + lv.lds_g1);
 }
 
-template <int DIM, int NT, int SPT, bool FUSED>
+template <int DIM, int NT, int SPT, bool FUSED, int RB = 0>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
-    auto kern = k_apply<DIM, NT, SPT, FUSED>;
+    auto kern = k_apply<DIM, NT, SPT, FUSED, RB>;
     if (FUSED && a.xcoarse) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -692,6 +909,8 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
     else if (nt <= 640)
         launch_apply_generic<DIM, 640, 11, FUSED>(L, lv, mesh, a, lds);
+    else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 1024 && !L.apply_unblocked)
+        launch_apply_generic<DIM, 1024, 7, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, lds);
     else
         launch_apply_generic<DIM, 1024, 7, FUSED>(L, lv, mesh, a, lds);
 }
@@ -991,8 +1210,17 @@ void launch_restrict(const Launch &L, const LevelDev &fine, const LevelDev &coar
 
 // ---------------------------------------------------------------------------------------------
 // streaming vector kernels (flat storage, every copy of a shared DOF counted -- BLAS semantics)
+//
+// Launch shape (profiles/r02_stream_variants.txt): ONE double2 per thread, 256-thread blocks, as many blocks as
+// there are pairs -- no grid-stride loop.  The dispatcher hands out blocks in order, so the ~2000 resident blocks
+// sweep one contiguous 8 MB window through every stream; a persistent grid-stride grid touches addresses one
+// grid-stride (8 MB) apart instead and loses 15 % (5.1 vs 6.0 TB/s on the 24 B/DOF update, 5.1 vs 6.3 TB/s on a
+// copy).  Reductions leave one partial per block in L.rpart (deterministic: fixed block order, two more stages).
 // ---------------------------------------------------------------------------------------------
-static inline int stream_blocks(const Launch &L, int64_t n, int per_thread)
+constexpr int SB = 256;   // threads per streaming block
+
+// grid of the kernels that keep a grid-stride loop (index arithmetic per element: permutation, synthetic fill, ...)
+static inline int strided_blocks(const Launch &L, int64_t n, int per_thread)
 {
     int64_t b = (n + (int64_t)256 * per_thread - 1) / ((int64_t)256 * per_thread);
     int64_t cap = (int64_t)L.num_cu * 8;
@@ -1001,33 +1229,50 @@ static inline int stream_blocks(const Launch &L, int64_t n, int per_thread)
     return (int)b;
 }
 
-__global__ void __launch_bounds__(256) k_fill(double *x, int64_t n, double v)
+static inline int64_t stream_blocks(int64_t n)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *x2 = reinterpret_cast<double2 *>(x);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) x2[i] = make_double2(v, v);
+    const int64_t b = ((n >> 1) + SB - 1) / SB;
+    return b < 1 ? 1 : b;
+}
+
+static void check_grid(int64_t nb)
+{
+    if (nb > 0x7fffffffLL) throw std::runtime_error("vector too long for one launch");
+}
+
+// block partials [nb] -> 256 partials in `out` (block b sums a contiguous range: fixed order)
+__global__ void __launch_bounds__(256) k_reduce_partials(const double *__restrict__ part, int64_t nb, double *out)
+{
+    __shared__ double red[4];
+    const int64_t per = (nb + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = (int64_t)blockIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
+    double a = 0.0;
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) a += part[i];
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(SB) k_fill(double *x, int64_t n, double v)
+{
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (i < (n >> 1)) reinterpret_cast<double2 *>(x)[i] = make_double2(v, v);
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = v;
 }
 
-__global__ void __launch_bounds__(256) k_copy(double *dst, const double *__restrict__ src, int64_t n)
+__global__ void __launch_bounds__(SB) k_copy(double *dst, const double *__restrict__ src, int64_t n)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *d2 = reinterpret_cast<double2 *>(dst);
-    const double2 *s2 = reinterpret_cast<const double2 *>(src);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) d2[i] = s2[i];
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (i < (n >> 1)) reinterpret_cast<double2 *>(dst)[i] = reinterpret_cast<const double2 *>(src)[i];
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
 }
 
-__global__ void __launch_bounds__(256) k_axpy(double a, const double *__restrict__ x, double *y, int64_t n)
+__global__ void __launch_bounds__(SB) k_axpy(double a, const double *__restrict__ x, double *y, int64_t n)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *y2 = reinterpret_cast<double2 *>(y);
-    const double2 *x2 = reinterpret_cast<const double2 *>(x);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        double2 xv = x2[i], yv = y2[i];
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (i < (n >> 1)) {
+        double2 *y2 = reinterpret_cast<double2 *>(y);
+        const double2 xv = reinterpret_cast<const double2 *>(x)[i];
+        double2 yv = y2[i];
         yv.x += a * xv.x;
         yv.y += a * xv.y;
         y2[i] = yv;
@@ -1035,14 +1280,13 @@ __global__ void __launch_bounds__(256) k_axpy(double a, const double *__restrict
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] += a * x[n - 1];
 }
 
-__global__ void __launch_bounds__(256) k_xpby(const double *__restrict__ r, double b, double *p, int64_t n)
+__global__ void __launch_bounds__(SB) k_xpby(const double *__restrict__ r, double b, double *p, int64_t n)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *p2 = reinterpret_cast<double2 *>(p);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        double2 rv = r2[i], pv = p2[i];
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (i < (n >> 1)) {
+        double2 *p2 = reinterpret_cast<double2 *>(p);
+        const double2 rv = reinterpret_cast<const double2 *>(r)[i];
+        double2 pv = p2[i];
         pv.x = rv.x + b * pv.x;
         pv.y = rv.y + b * pv.y;
         p2[i] = pv;
@@ -1050,37 +1294,31 @@ __global__ void __launch_bounds__(256) k_xpby(const double *__restrict__ r, doub
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + b * p[n - 1];
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SB)
 k_dot(const double *__restrict__ x, const double *__restrict__ y, int64_t n, double *partials)
 {
     __shared__ double red[4];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    const double2 *x2 = reinterpret_cast<const double2 *>(x);
-    const double2 *y2 = reinterpret_cast<const double2 *>(y);
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        double2 xv = x2[i], yv = y2[i];
+    if (i < (n >> 1)) {
+        const double2 xv = reinterpret_cast<const double2 *>(x)[i], yv = reinterpret_cast<const double2 *>(y)[i];
         acc += xv.x * yv.x;
         acc += xv.y * yv.y;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc += x[n - 1] * y[n - 1];
-    double s = block_sum(acc, red);
+    const double s = block_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SB)
 k_copy_dot(double *p, const double *__restrict__ r, int64_t n, double *partials)
 {
     __shared__ double red[4];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *p2 = reinterpret_cast<double2 *>(p);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        double2 rv = r2[i];
-        p2[i] = rv;
+    if (i < (n >> 1)) {
+        const double2 rv = reinterpret_cast<const double2 *>(r)[i];
+        reinterpret_cast<double2 *>(p)[i] = rv;
         acc += rv.x * rv.x;
         acc += rv.y * rv.y;
     }
@@ -1088,25 +1326,23 @@ k_copy_dot(double *p, const double *__restrict__ r, int64_t n, double *partials)
         p[n - 1] = r[n - 1];
         acc += r[n - 1] * r[n - 1];
     }
-    double s = block_sum(acc, red);
+    const double s = block_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SB)
 k_cg_update(double *x, double *r, const double *__restrict__ p, const double *__restrict__ q, int64_t n,
             const double *__restrict__ scal, int s_num, int s_den, double *partials)
 {
     __shared__ double red[4];
     const double alpha = scal[s_num] / scal[s_den];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *x2 = reinterpret_cast<double2 *>(x);
-    double2 *r2 = reinterpret_cast<double2 *>(r);
-    const double2 *p2 = reinterpret_cast<const double2 *>(p);
-    const double2 *q2 = reinterpret_cast<const double2 *>(q);
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        double2 xv = x2[i], rv = r2[i], pv = p2[i], qv = q2[i];
+    if (i < (n >> 1)) {
+        double2 *x2 = reinterpret_cast<double2 *>(x);
+        double2 *r2 = reinterpret_cast<double2 *>(r);
+        double2 xv = x2[i], rv = r2[i];
+        const double2 pv = reinterpret_cast<const double2 *>(p)[i], qv = reinterpret_cast<const double2 *>(q)[i];
         xv.x += alpha * pv.x;
         xv.y += alpha * pv.y;
         rv.x += (-alpha) * qv.x;
@@ -1122,29 +1358,26 @@ k_cg_update(double *x, double *r, const double *__restrict__ p, const double *__
         r[n - 1] = rv;
         acc += rv * rv;
     }
-    double s = block_sum(acc, red);
+    const double s = block_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 // rout = r - alpha q, partial rout.rout   (alpha = scal[s_num] / scal[s_den]; rout may be r); the x-update rides with
 // the next fused apply
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SB)
 k_cg_rupdate(const double *r, double *rout, const double *__restrict__ q, int64_t n, const double *__restrict__ scal,
              int s_num, int s_den, double *partials)
 {
     __shared__ double red[4];
     const double alpha = scal[s_num] / scal[s_den];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    const double2 *r2 = reinterpret_cast<const double2 *>(r);
-    double2 *o2 = reinterpret_cast<double2 *>(rout);
-    const double2 *q2 = reinterpret_cast<const double2 *>(q);
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        double2 rv = r2[i], qv = q2[i];
+    if (i < (n >> 1)) {
+        double2 rv = reinterpret_cast<const double2 *>(r)[i];
+        const double2 qv = reinterpret_cast<const double2 *>(q)[i];
         rv.x += (-alpha) * qv.x;
         rv.y += (-alpha) * qv.y;
-        o2[i] = rv;
+        reinterpret_cast<double2 *>(rout)[i] = rv;
         acc += rv.x * rv.x;
         acc += rv.y * rv.y;
     }
@@ -1153,29 +1386,28 @@ k_cg_rupdate(const double *r, double *rout, const double *__restrict__ q, int64_
         rout[n - 1] = rv;
         acc += rv * rv;
     }
-    double s = block_sum(acc, red);
+    const double s = block_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
 // x += alpha p (alpha = scal[a_num]/scal[a_den]) and, if with_p, p = r + beta p (beta = scal[s_num]/scal[s_den])
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SB)
 k_cg_xp_update(double *x, double *p, const double *__restrict__ r, int64_t n, const double *__restrict__ scal,
                int a_num, int a_den, int s_num, int s_den, int with_p)
 {
     const double alpha = scal[a_num] / scal[a_den];
     const double beta = with_p ? scal[s_num] / scal[s_den] : 0.0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *x2 = reinterpret_cast<double2 *>(x);
-    double2 *p2 = reinterpret_cast<double2 *>(p);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (i < (n >> 1)) {
+        double2 *x2 = reinterpret_cast<double2 *>(x);
+        double2 *p2 = reinterpret_cast<double2 *>(p);
         double2 xv = x2[i], pv = p2[i];
+        double2 rv = make_double2(0.0, 0.0);
+        if (with_p) rv = reinterpret_cast<const double2 *>(r)[i];
         xv.x += alpha * pv.x;
         xv.y += alpha * pv.y;
         x2[i] = xv;
         if (with_p) {
-            double2 rv = r2[i];
             pv.x = rv.x + beta * pv.x;
             pv.y = rv.y + beta * pv.y;
             p2[i] = pv;
@@ -1187,16 +1419,15 @@ k_cg_xp_update(double *x, double *p, const double *__restrict__ r, int64_t n, co
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SB)
 k_cg_pupdate(double *p, const double *__restrict__ r, int64_t n, const double *__restrict__ scal, int s_num, int s_den)
 {
     const double beta = scal[s_num] / scal[s_den];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n2 = n >> 1;
-    double2 *p2 = reinterpret_cast<double2 *>(p);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
-        double2 rv = r2[i], pv = p2[i];
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    if (i < (n >> 1)) {
+        double2 *p2 = reinterpret_cast<double2 *>(p);
+        const double2 rv = reinterpret_cast<const double2 *>(r)[i];
+        double2 pv = p2[i];
         pv.x = rv.x + beta * pv.x;
         pv.y = rv.y + beta * pv.y;
         p2[i] = pv;
@@ -1210,69 +1441,106 @@ static void finalize(const Launch &L, int nb, int slot)
     check_launch();
 }
 
+// Where a streaming reduction over nb blocks leaves its partials, and how they become scal[slot]: few blocks go to the
+// small buffer and one finalize; many go to L.rpart, are folded to 256 partials, then finalized.
+static double *reduce_target(const Launch &L, int64_t nb)
+{
+    if (nb <= 2048) return L.partials;
+    if (!L.rpart || nb > L.rpart_cap) throw std::runtime_error("reduction scratch too small for this vector");
+    return L.rpart;
+}
+
+static void reduce_finish(const Launch &L, int64_t nb, int slot)
+{
+    if (nb <= 2048) {
+        finalize(L, (int)nb, slot);
+        return;
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(256), dim3(256), 0, L.stream, L.rpart, nb, L.partials);
+    check_launch();
+    finalize(L, 256, slot);
+}
+
 void launch_fill(const Launch &L, double *x, int64_t n, double v)
 {
-    hipLaunchKernelGGL(k_fill, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, x, n, v);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)nb), dim3(SB), 0, L.stream, x, n, v);
     check_launch();
 }
 void launch_copy(const Launch &L, double *dst, const double *src, int64_t n)
 {
-    hipLaunchKernelGGL(k_copy, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, dst, src, n);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)nb), dim3(SB), 0, L.stream, dst, src, n);
     check_launch();
 }
 void launch_axpy(const Launch &L, double a, const double *x, double *y, int64_t n)
 {
-    hipLaunchKernelGGL(k_axpy, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, a, x, y, n);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned)nb), dim3(SB), 0, L.stream, a, x, y, n);
     check_launch();
 }
 void launch_xpby(const Launch &L, const double *r, double b, double *p, int64_t n)
 {
-    hipLaunchKernelGGL(k_xpby, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, r, b, p, n);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_xpby, dim3((unsigned)nb), dim3(SB), 0, L.stream, r, b, p, n);
     check_launch();
 }
 void launch_dot(const Launch &L, const double *x, const double *y, int64_t n, int slot)
 {
-    int nb = stream_blocks(L, n, 8);
-    hipLaunchKernelGGL(k_dot, dim3(nb), dim3(256), 0, L.stream, x, y, n, L.partials);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_dot, dim3((unsigned)nb), dim3(SB), 0, L.stream, x, y, n, reduce_target(L, nb));
     check_launch();
-    finalize(L, nb, slot);
+    reduce_finish(L, nb, slot);
 }
 void launch_copy_dot(const Launch &L, double *p, const double *r, int64_t n, int slot)
 {
-    int nb = stream_blocks(L, n, 8);
-    hipLaunchKernelGGL(k_copy_dot, dim3(nb), dim3(256), 0, L.stream, p, r, n, L.partials);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_copy_dot, dim3((unsigned)nb), dim3(SB), 0, L.stream, p, r, n, reduce_target(L, nb));
     check_launch();
-    finalize(L, nb, slot);
+    reduce_finish(L, nb, slot);
 }
 void launch_cg_update(const Launch &L, double *x, double *r, const double *p, const double *q, int64_t n, int s_num,
                       int s_den, int s_out)
 {
-    int nb = stream_blocks(L, n, 8);
-    hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, L.stream, x, r, p, q, n, L.scal, s_num, s_den, L.partials);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_cg_update, dim3((unsigned)nb), dim3(SB), 0, L.stream, x, r, p, q, n, L.scal, s_num, s_den,
+                       reduce_target(L, nb));
     check_launch();
-    finalize(L, nb, s_out);
+    reduce_finish(L, nb, s_out);
 }
 void launch_cg_rupdate(const Launch &L, const double *r, double *rout, const double *q, int64_t n, int s_num, int s_den,
                        int s_out)
 {
-    int nb = stream_blocks(L, n, 8);
-    hipLaunchKernelGGL(k_cg_rupdate, dim3(nb), dim3(256), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den, L.partials);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_cg_rupdate, dim3((unsigned)nb), dim3(SB), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den,
+                       reduce_target(L, nb));
     check_launch();
-    finalize(L, nb, s_out);
+    reduce_finish(L, nb, s_out);
 }
 
 void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
                          int s_num, int s_den, int with_p)
 {
-    hipLaunchKernelGGL(k_cg_xp_update, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, x, p, r, n, L.scal, a_num,
-                       a_den, s_num, s_den, with_p);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_cg_xp_update, dim3((unsigned)nb), dim3(SB), 0, L.stream, x, p, r, n, L.scal, a_num, a_den, s_num,
+                       s_den, with_p);
     check_launch();
 }
 
 void launch_cg_pupdate(const Launch &L, double *p, const double *r, int64_t n, int s_num, int s_den)
 {
-    hipLaunchKernelGGL(k_cg_pupdate, dim3(stream_blocks(L, n, 8)), dim3(256), 0, L.stream, p, r, n, L.scal, s_num,
-                       s_den);
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_cg_pupdate, dim3((unsigned)nb), dim3(SB), 0, L.stream, p, r, n, L.scal, s_num, s_den);
     check_launch();
 }
 
@@ -1391,7 +1659,7 @@ k_permute(LevelDev lv, int64_t ncells, const double *__restrict__ src, double *d
 
 void launch_permute(const Launch &L, const LevelDev &lv, int64_t ncells, const double *src, double *dst, int to_storage)
 {
-    hipLaunchKernelGGL(k_permute, dim3(stream_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, src,
+    hipLaunchKernelGGL(k_permute, dim3(strided_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, src,
                        dst, to_storage);
     check_launch();
 }
@@ -1422,7 +1690,7 @@ k_fill_random(LevelDev lv, int64_t ncells, double *x, uint64_t seed, int64_t cel
 void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, double *x, uint64_t seed,
                         int64_t cell_offset)
 {
-    hipLaunchKernelGGL(k_fill_random, dim3(stream_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, x,
+    hipLaunchKernelGGL(k_fill_random, dim3(strided_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, x,
                        seed, cell_offset);
     check_launch();
 }
@@ -1691,7 +1959,7 @@ k_rhs_dphi(LevelDev lv, int64_t ncells, const double *__restrict__ pvec, double 
 
 void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const double *pvec, double *b)
 {
-    hipLaunchKernelGGL(k_rhs_dphi, dim3(stream_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, pvec,
+    hipLaunchKernelGGL(k_rhs_dphi, dim3(strided_blocks(L, ncells * lv.nf, 4)), dim3(256), 0, L.stream, lv, ncells, pvec,
                        b);
     check_launch();
 }
@@ -1724,7 +1992,7 @@ void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nent
                      const int32_t *cell_lid, const uint8_t *first, double *buf, double *x, int unpack)
 {
     const int per = kind == 0 ? lv.nfi : kind == 1 ? lv.nei : 1;
-    hipLaunchKernelGGL(k_cut_pack, dim3(stream_blocks(L, nentries * per, 1)), dim3(256), 0, L.stream, lv, kind,
+    hipLaunchKernelGGL(k_cut_pack, dim3(strided_blocks(L, nentries * per, 1)), dim3(256), 0, L.stream, lv, kind,
                        nentries, gid, cell_lid, first, buf, x, unpack);
     check_launch();
 }

@@ -312,7 +312,7 @@ std::vector<LevelTables> build_level_tables(int dim, int nlevels)
         // kernels clamp those to 0 instead of paying a front guard zone of ~T(m+2) doubles of LDS per cell.
         if (amin_interior < 0) throw std::runtime_error("reference lattice: an interior node addresses below 0");
         T.lds_g0 = 0;
-        T.lds_g1 = amax - (nf - 1);
+        T.lds_g1 = std::max(amax - (nf - 1), dim == 3 ? m + 8 : 0);   // (3D: the blocked interior reads whole 7-point plane stars)
         (void)amin;
 
         // interior sweep: rows (j,k) that contain cell-interior nodes, all positions i = 0..len-1

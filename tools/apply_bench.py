@@ -15,11 +15,14 @@ ap.add_argument("--levels", type=int, default=6)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--threads", type=int, default=None)
 ap.add_argument("--mode", default="ap")
+ap.add_argument("--unblocked", action="store_true", help="node-per-thread interior sweep (round-1 kernel) for A/B runs")
 ap.add_argument("--others", action="store_true", help="also time interface sum / vector kernels / transfer")
 a = ap.parse_args()
 ctx = hmg.Context(0)
 if a.threads is not None:
     ctx.set_option("apply_threads", a.threads)
+if a.unblocked:
+    ctx.set_option("apply_unblocked", 1)
 L = a.levels
 base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, a.width, L, seed=0)
 x = hmg.DeviceMatrix(g, L).rand(1)
