@@ -361,7 +361,15 @@ static void upload_levels(hmg_grid *g)
                         for (int t = 0; t < T.nterm; ++t) zero = zero && T.ctab[((size_t)(1 + f) * T.ndir + d) * T.nterm + t] == 0.0;
                         if (((absent[f] >> d) & 1u) && !zero) ok = false;   // a tap the kernel skips carries weight
                     }
-                if (!ok) throw std::runtime_error("blocked apply: the class table does not match the kernel's face tap masks");
+                // edges (pipelined kernel): an edge node keeps the taps both of its faces keep (edge_tap_mask)
+                static const int ef[6][2] = {{0, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {2, 3}};
+                for (int e = 0; ok && e < T.nedge && T.nedge == 6; ++e)
+                    for (int d = 0; d < T.ndir; ++d) {
+                        bool zero = true;
+                        for (int t = 0; t < T.nterm; ++t) zero = zero && T.ctab[((size_t)(1 + T.nface + e) * T.ndir + d) * T.nterm + t] == 0.0;
+                        if ((((absent[ef[e][0]] | absent[ef[e][1]]) >> d) & 1u) && !zero) ok = false;
+                    }
+                if (!ok) throw std::runtime_error("blocked apply: the class table does not match the kernel's face / edge tap masks");
                 B.nblk = (int)bw.size();
                 B.blk_R = R;
                 bw.resize(bw.size() + TABLE_PAD, 0u);
@@ -1150,6 +1158,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_threads = 0;
     c->L.apply_mass_only = 0;
     c->L.apply_unblocked = 0;
+    c->L.apply_pipe = 0;   // experimental (measured slower than k_apply inside the V-cycle)
     *out = c.release();
     HMG_END
 }
@@ -1187,6 +1196,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
 
     else if (n == "apply_unblocked")
         ctx->L.apply_unblocked = value != 0;
+    else if (n == "apply_pipe")
+        ctx->L.apply_pipe = (int)value;
     else if (n == "coarse_maxit")
         ctx->coarse_maxit = (int)value;
     else if (n == "coarse_check")
