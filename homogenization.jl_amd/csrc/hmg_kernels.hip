@@ -58,7 +58,10 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // Class weight table of this cell: W[class][dir] = sum_t ctab[class][dir][t] * s[t].  Done by the LAST
     // waves of the workgroup (their share of the column load below is the smallest), while the others are
     // already issuing their column loads -- the table's L2 latency then overlaps the HBM latency.
-    if (tid >= NT - 256 || NT <= 256) {
+    // RB instantiations share no weight table: every wave combines the class rows it needs itself (below, behind its
+    // column loads); the cell's coefficients are requested first, one per lane
+    const double cv = RB ? coef[cell * 8 + (tid & 7)] : 0.0;
+    if (!RB && (tid >= NT - 256 || NT <= 256)) {
         double s[NTERM];
         cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
         const int first = NT <= 256 ? tid : tid - (NT - 256);
@@ -178,22 +181,41 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const int nsurf = lv.off_int;
     // (pos32 / sweep32 / sweep_slot carry TABLE_PAD entries of padding -- zero words, slot 0xffff -- so the
     //  two-ahead prefetch needs no bounds checks and both loops have a wave-uniform trip count)
-    // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the last wave takes the
-    // corners and edges (EI runs) instead of an interior block -- the 945 blocks of level 6 fill waves 0..14.
-    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, FI = 2, EI = 3;
+    // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the last 6 waves take one
+    // edge each, the last wave the corners instead of an interior block -- the 945 blocks of level 6 fill waves 0..14.
+    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, FI = 2;
     const int wave = tid >> 6, lane = tid & 63;
     const int face = wave / WPF, ft0 = (wave % WPF) * (FI * 64);
-    uint32_t fw[FI] = {0u, 0u}, ew[EI] = {0u, 0u, 0u};
+    const int edge = wave - (NW - 6), ebase = lv.off_edge + (edge < 0 ? 0 : edge) * lv.nei;
+    uint32_t fw[FI] = {0u, 0u}, ew[1] = {0u}, cw = 0u;
     uint32_t p0 = 0u, p1 = 0u;
+    double wv = 0.0;                 // RB: lane d: interior weight d; lane 16 + d: this wave's face; lane 32 + d: its edge
     if (RB) {
 #pragma unroll
         for (int q = 0; q < FI; ++q) {
             const int ti = ft0 + q * 64 + lane;
             if (ti < lv.nfi) fw[q] = lv.pos32[lv.off_face + face * lv.nfi + ti];
         }
-        if (wave == NW - 1) {
+        if (edge >= 0 && lane < lv.nei) ew[0] = lv.pos32[ebase + lane];
+        if (wave == NW - 1 && lane < lv.ncorner) cw = lv.pos32[lane];
+        // class rows (L2-resident table) x the cell's 7 scales
+        const int row = lane < 15 ? lane : (lane >= 16 && lane < 31) ? (1 + face) * NDIR + lane - 16
+                        : (lane >= 32 && lane < 47 && edge >= 0) ? (1 + lv.nface + edge) * NDIR + lane - 32 : 0;
+        double c7[NTERM], sc7[NTERM];
 #pragma unroll
-            for (int q = 0; q < EI; ++q) ew[q] = lv.pos32[q * 64 + lane];     // (table is padded)
+        for (int t = 0; t < NTERM; ++t) c7[t] = lv.ctab[(size_t)row * NTERM + t];
+#pragma unroll
+        for (int t = 0; t < NTERM - 1; ++t) sc7[t] = (a.flags & 2) ? 0.0 : a.alpha * readlane_f64(cv, t);
+        sc7[NTERM - 1] = a.alpha * a.lambda * readlane_f64(cv, NTERM - 1);
+#pragma unroll
+        for (int t = 0; t < NTERM; ++t) wv += c7[t] * sc7[t];
+        if (wave == NW - 1) {        // the corners' rows: per-lane weights, private to this wave (LDS ops of a wave are in order)
+            for (int idx = (1 + lv.nface + lv.nedge) * NDIR + lane; idx < lv.ncls * NDIR; idx += 64) {
+                double w = 0.0;
+#pragma unroll
+                for (int t = 0; t < NTERM; ++t) w += lv.ctab[(size_t)idx * NTERM + t] * sc7[t];
+                W[idx] = w;
+            }
         }
     } else {
         p0 = lv.pos32[tid];
@@ -237,23 +259,30 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             const bool fdir = (dm >> face) & 1u;
             const double fmult = (double)((mq[0] >> (8 * face)) & 0xffu);
             const int fbase = lv.off_face + face * lv.nfi;
-            const double fwv = lds_ld(W + (1 + face) * 15 + (lane < 15 ? lane : 0));   // the face's weight row, lane d <- w[d]
             const double nopre[FI] = {0.0, 0.0};
             if (face == 0)
-                face_items<0, FI, FUSED>(fwv, 0, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+                face_items<0, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
             else if (face == 1)
-                face_items<1, FI, FUSED>(fwv, 0, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+                face_items<1, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
             else if (face == 2)
-                face_items<2, FI, FUSED>(fwv, 0, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+                face_items<2, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
             else
-                face_items<3, FI, FUSED>(fwv, 0, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
-            if (wave == NW - 1) {
-#pragma unroll
-                for (int q = 0; q < EI; ++q) {
-                    const int t = q * 64 + lane;
-                    if (t < lv.off_face) surface_node(t, ew[q]);
+                face_items<3, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+            if (edge >= 0) {
+                const int eb = lv.nface + edge;
+                const bool edir = (dm >> eb) & 1u;
+                const double emult = (double)(((eb < 4 ? mq[0] : eb < 8 ? mq[1] : mq[2]) >> (8 * (eb & 3))) & 0xffu);
+                const double nop1[1] = {0.0};
+                switch (edge) {
+                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
+                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
+                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
+                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
+                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
+                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
                 }
             }
+            if (wave == NW - 1 && lane < lv.ncorner) surface_node(lane, cw);
         }
     } else {
         const int nit_surf = (nsurf + NT - 1) / NT;
@@ -269,7 +298,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // cell interior: one weight row for all nodes
     double w0[15];
 #pragma unroll
-    for (int d = 0; d < NDIR; ++d) w0[d] = to_sgpr(W[d]);
+    for (int d = 0; d < NDIR; ++d) w0[d] = RB ? readlane_f64(wv, d) : to_sgpr(W[d]);
     if (RB) {
         // register-blocked interior: one pass (the host selects this instantiation only if nblk <= NT), its word
         // was fetched before the barrier
@@ -578,7 +607,7 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
     else if (nt <= 640)
         launch_apply_generic<DIM, 640, 11, FUSED>(L, lv, mesh, a, lds);
-    else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 1024 && !L.apply_unblocked)
+    else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked)
         launch_apply_generic<DIM, 1024, 7, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, lds);
     else
         launch_apply_generic<DIM, 1024, 7, FUSED>(L, lv, mesh, a, lds);
