@@ -393,9 +393,18 @@ def _integrate(implicit, mode, v, vprev, nsub, xi):
     return out.value
 
 
-def integrate_first_term(v0: DeviceMatrix, implicit: ImplicitFineGrid, nsubset: int, xi) -> float:
-    """sum over the first `nsubset` cells of |J| * v0.(dphi.P + M v0)  (src/examples/homogenized_coefficients.jl:592-632)"""
-    return _integrate(implicit, 0, v0, None, nsubset, xi)
+def integrate_first_term(v0: DeviceMatrix, implicit: ImplicitFineGrid, nsubset: int, xi, b: DeviceMatrix = None) -> float:
+    """sum over the first `nsubset` cells of |J| * v0.(dphi.P + M v0)  (src/examples/homogenized_coefficients.jl:592-632).
+    dphi.P is the entry of rhs_a xi grad v! for the same xi: pass that vector as `b` (the driver's right-hand side of
+    outer step 0); without it a temporary is filled."""
+    if b is None:
+        b = v0.similar()
+        rhs_axi_grad_v(b, implicit, xi)
+        try:
+            return _integrate(implicit, 0, v0, b, nsubset, xi)
+        finally:
+            b.close()
+    return _integrate(implicit, 0, v0, b, nsubset, xi)
 
 
 def integrate_terms(vk: DeviceMatrix, vkm1: DeviceMatrix, implicit: ImplicitFineGrid, nsubset: int) -> float:

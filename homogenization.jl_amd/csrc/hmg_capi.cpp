@@ -1859,23 +1859,6 @@ int hmg_local_rhs(hmg_grid *g, hmg_vec *b)
     HMG_END
 }
 
-static std::vector<double> axi_pvec(const hmg_grid *g, const MeshTables &M, const double *xi, int64_t ncells)
-{
-    // P = -detJ * (Jinv' * (sigma .* xi))   (ref: ...homogenized_coefficients.jl:468, :611)
-    const int dim = g->dim;
-    std::vector<double> pv((size_t)ncells * 3, 0.0);
-    for (int64_t c = 0; c < ncells; ++c) {
-        const double *Ji = &M.jinv[(size_t)c * dim * dim];
-        const double *sg = &g->sigma[(size_t)c * dim];
-        for (int a = 0; a < dim; ++a) {
-            double s = 0.0;
-            for (int k = 0; k < dim; ++k) s += Ji[k + dim * a] * (sg[k] * xi[k]);
-            pv[(size_t)c * 3 + a] = -M.detj[c] * s;
-        }
-    }
-    return pv;
-}
-
 int hmg_integrate(hmg_grid *g, int mode, hmg_vec *v, hmg_vec *vprev, int64_t ncells_subset, const double *xi, double *out)
 {
     HMG_TRY
@@ -1897,16 +1880,13 @@ int hmg_integrate(hmg_grid *g, int mode, hmg_vec *v, hmg_vec *vprev, int64_t nce
         *out = 0.0;
         return 0;
     }
-    DevBuf<double> d;
-    if (mode == 0) {
-        need(xi != nullptr, "xi required for the first term");
-        d.upload(axi_pvec(g, M, xi, ncells_subset), g->ctx->stream);
-    } else {
-        need(vprev != nullptr, "vprev required");
-        check_vec(g, v->level, vprev, "vprev");
-    }
-    launch_integrate(g->ctx->L, lev(g, v->level), g->md, mode, ncells_subset, v->d, vprev ? vprev->d : nullptr, d.p,
-                     S_TMP);
+    need(vprev != nullptr, mode == 0 ? "mode 0 needs the right-hand side rhs_a.xi.grad(v) (hmg_rhs_axi_grad) as second vector"
+                                     : "mode 1 needs the previous iterate as second vector");
+    check_vec(g, v->level, vprev, "second vector");
+    need(v->d != vprev->d, "the two vectors must not alias");
+    (void)xi;   // (mode 0: the direction already sits in the right-hand side the caller passes)
+    set_slab(g, lev(g, v->level));
+    launch_integrate(g->ctx->L, lev(g, v->level), g->md, mode, ncells_subset, v->d, vprev->d, S_TMP);
     *out = read_scalar(g->ctx, S_TMP);
     HMG_END
 }

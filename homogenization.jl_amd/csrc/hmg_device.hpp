@@ -88,7 +88,10 @@ struct ApplyArgs {
     double *blockpart;
     const uint8_t *mult;
     int flags;             // bit 0: Dirichlet constraint on out; bit 1: mass term only; bit 2 (slab kernel): weights =
-                           // last term of the class table, no per-cell scaling (restriction)
+                           // last term of the class table, no per-cell scaling (restriction); bit 3 (fused): src
+                           // multiplies instead of being added, sum mult (x + src) out; bit 4: mass term not scaled
+                           // by |J|; bit 5 (fused): unit multiplicities
+    int64_t ncells_prefix; // > 0: only the first ncells_prefix cells
     int64_t out_ld;        // column stride of out if it differs from the level's (slab restriction), else 0
     const int32_t *cell_list;   // optional: workgroup b works on cell cell_list[b] (ncell_list of them)
     int64_t ncell_list;
@@ -197,9 +200,9 @@ void launch_coarse_residual_norm(const Launch &L, const CoarseDev &A);   // scal
 // b[slot, cell] = dot(dphi[slot], pvec[cell])   (rhs_a xi grad v)
 void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const double *pvec, double *b);
 
-// scal[slot] = integral over the first nsub cells (mode 0: first term, needs pvec; mode 1: needs w2)
+// scal[slot] = integral over the first nsub cells; second = b (mode 0, first term) / the previous iterate (mode 1)
 void launch_integrate(const Launch &L, const LevelDev &lv, const MeshDev &mesh, int mode, int64_t nsub, const double *v,
-                      const double *w2, const double *pvec, int slot);
+                      const double *second, int slot);
 
 // multi-GPU cut exchange: unpack = 0 packs buf[gid] <- x (first local copy), 1 writes x <- buf[gid]
 void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nentries, const int64_t *gid,

@@ -63,7 +63,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const double cv = RB ? coef[cell * 8 + (tid & 7)] : 0.0;
     if (!RB && (tid >= NT - 256 || NT <= 256)) {
         double s[NTERM];
-        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
+        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags);
         const int first = NT <= 256 ? tid : tid - (NT - 256);
         const int step = NT <= 256 ? NT : 256;
         for (int idx = first; idx < lv.ncls * NDIR; idx += step) {
@@ -206,7 +206,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         for (int t = 0; t < NTERM; ++t) c7[t] = lv.ctab[(size_t)row * NTERM + t];
 #pragma unroll
         for (int t = 0; t < NTERM - 1; ++t) sc7[t] = (a.flags & 2) ? 0.0 : a.alpha * readlane_f64(cv, t);
-        sc7[NTERM - 1] = a.alpha * a.lambda * readlane_f64(cv, NTERM - 1);
+        sc7[NTERM - 1] = a.alpha * a.lambda * ((a.flags & 16) ? 1.0 : readlane_f64(cv, NTERM - 1));
 #pragma unroll
         for (int t = 0; t < NTERM; ++t) wv += c7[t] * sc7[t];
         if (wave == NW - 1) {        // the corners' rows: per-lane weights, private to this wave (LDS ops of a wave are in order)
@@ -232,8 +232,9 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     if (FUSED) {
         const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mq[q] = __builtin_amdgcn_readfirstlane(mp[q]);
+        for (int q = 0; q < 4; ++q) mq[q] = a.mult ? __builtin_amdgcn_readfirstlane(mp[q]) : 0x01010101u;   // (no table: all 1)
     }
+    const bool wdot = FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
     HMG_STAMP(2);   // tables requested, before the barrier
     __syncthreads();
     HMG_STAMP(3);
@@ -244,14 +245,15 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         int L, len, A, B, cls;
         decode32<DIM>(pw, m, L, len, A, B, cls);
         double ctr;
-        double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+        double o = stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+        if (!wdot) o = sv + o;
         if ((dm >> (cls - 1)) & 1u) o = 0.0;
         if (!FUSED || oc) oc[t] = o;
         if (FUSED) {
             const int e = cls - 1;
             const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
             const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
-            pap += (double)mu * (ctr * o);
+            pap += (double)mu * ((wdot ? ctr + sv : ctr) * o);
         }
     };
     if (RB) {
@@ -261,25 +263,25 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             const int fbase = lv.off_face + face * lv.nfi;
             const double nopre[FI] = {0.0, 0.0};
             if (face == 0)
-                face_items<0, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+                face_items<0, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
             else if (face == 1)
-                face_items<1, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+                face_items<1, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
             else if (face == 2)
-                face_items<2, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+                face_items<2, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
             else
-                face_items<3, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false);
+                face_items<3, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
             if (edge >= 0) {
                 const int eb = lv.nface + edge;
                 const bool edir = (dm >> eb) & 1u;
                 const double emult = (double)(((eb < 4 ? mq[0] : eb < 8 ? mq[1] : mq[2]) >> (8 * (eb & 3))) & 0xffu);
                 const double nop1[1] = {0.0};
                 switch (edge) {
-                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
-                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
-                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
-                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
-                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
-                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false); break;
+                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
                 }
             }
             if (wave == NW - 1 && lane < lv.ncorner) surface_node(lane, cw);
@@ -304,7 +306,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // was fetched before the barrier
         if (DIM == 3 && tid < nsw) {
             if (sc)
-                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap);
+                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap, wdot);
             else
                 interior_block<RB ? RB : 1, FUSED, false>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap);
         }
@@ -323,9 +325,10 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 int L, len, A, B, cls;
                 decode32<DIM>(pw, m, L, len, A, B, cls);
                 double ctr;
-                const double o = sv + stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
+                double o = stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
+                if (!wdot) o = sv + o;
                 if (!FUSED || oc) oc[t] = o;
-                if (FUSED) pap += ctr * o;
+                if (FUSED) pap += (wdot ? ctr + sv : ctr) * o;
             }
         }
     }
@@ -370,7 +373,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
         for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) W[idx] = lv.ctab[(size_t)idx * NTERM + NTERM - 1];
     } else {
         double s[NTERM];
-        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags & 2);
+        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags);
         for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) {
             const double *c = lv.ctab + (size_t)idx * NTERM;
             double w = 0.0;
@@ -394,8 +397,9 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     if (FUSED) {
         const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mq[q] = __builtin_amdgcn_readfirstlane(mp[q]);
+        for (int q = 0; q < 4; ++q) mq[q] = a.mult ? __builtin_amdgcn_readfirstlane(mp[q]) : 0x01010101u;
     }
+    const bool wdot = FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
     double rr = 0.0, pap = 0.0;
     auto plane_off = [&](int k) {   // PO(k) = number of lattice nodes in planes < k
         if (k <= 0) return 0;
@@ -491,14 +495,15 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
                 int L, len, A, B, cls, k;
                 decode32w(pw, m, L, len, A, B, cls, k);
                 double ctr;
-                double o = sv + stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+                double o = stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+                if (!wdot) o = sv + o;
                 if ((dm >> (cls - 1)) & 1u) o = 0.0;
                 if (!FUSED || oc) oc[t] = o;
                 if (FUSED) {
                     const int en = cls - 1;
                     const uint32_t word = en < 4 ? mq[0] : en < 8 ? mq[1] : en < 12 ? mq[2] : mq[3];
                     const uint32_t mu = (word >> (8 * (en & 3))) & 0xffu;
-                    pap += (double)mu * (ctr * o);
+                    pap += (double)mu * ((wdot ? ctr + sv : ctr) * o);
                 }
             }
         }
@@ -517,9 +522,10 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
                 int L, len, A, B, cls, k;
                 decode32w(pw, m, L, len, A, B, cls, k);
                 double ctr;
-                const double o = sv + stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
+                double o = stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
+                if (!wdot) o = sv + o;
                 if (!FUSED || oc) oc[t] = o;
-                if (FUSED) pap += ctr * o;
+                if (FUSED) pap += (wdot ? ctr + sv : ctr) * o;
             }
         }
         lo_prev = lo;
@@ -553,6 +559,18 @@ k_reduce_pairs(const double *__restrict__ blockpart, int64_t n, double *partials
     }
 }
 
+// driver integrals: sum over the first n cells of |J_c| * blockpart[2 c]  (|J| = last term of the cell's coefficients)
+__global__ void __launch_bounds__(256)
+k_reduce_weighted(const double *__restrict__ blockpart, const double *__restrict__ coef, int jterm, int64_t n, double *partials)
+{
+    __shared__ double red[4];
+    double s0 = 0.0;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256)
+        s0 += blockpart[2 * c] * coef[c * 8 + jterm];
+    const double r0 = block_sum(s0, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r0;
+}
+
 size_t apply_lds_bytes(const LevelDev &lv)
 {
     return sizeof(double) * (size_t)(WSZ + lv.lds_g0 + lv.nf + lv.lds_g1);
@@ -565,7 +583,7 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
     if (FUSED && a.xcoarse) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t nblocks = a.cell_list ? a.ncell_list : mesh.ncells;
+    const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
     if (nblocks == 0) return;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, a);
     check_launch();
@@ -580,7 +598,7 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         auto kern = k_apply_slab<3, 1024, FUSED>;
         const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab.lds_nodes);
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        const int64_t nblocks = a.cell_list ? a.ncell_list : mesh.ncells;
+        const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
         if (nblocks == 0) return;
         hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
                            mesh.slab);
@@ -644,7 +662,7 @@ void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh,
 void launch_apply_fused_kernel(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a)
 {
     a.scal = L.scal;
-    a.mult = mesh.mult;
+    if (!(a.flags & 32)) a.mult = mesh.mult;     // (bit 5: caller wants unit multiplicities -- a.mult stays null)
     a.blockpart = mesh.blockpart;
     if (lv.dim == 3)
         launch_apply_dim<3, true>(L, lv, mesh, a);
@@ -1558,80 +1576,26 @@ void launch_coarse_residual_norm(const Launch &L, const CoarseDev &A)
 
 // ---------------------------------------------------------------------------------------------
 // driver integrals over a prefix of cells (ref: src/examples/homogenized_coefficients.jl:592-667)
-//   mode 0: sum_cells |J| sum_i v_i (dphi_i . P_cell + (M v)_i)          integrate_first_term
-//   mode 1: sum_cells |J| sum_i (v_i + w_i) (M v)_i                      integrate_terms
-// M = reference-element mass matrix of the level (mass term of the class stencil, unscaled).
+//   mode 0: sum_cells |J| sum_i v_i (b_i + (M v)_i), b = dphi . P = the right-hand side of outer step 0   integrate_first_term
+//   mode 1: sum_cells |J| sum_i (v_i + w_i) (M v)_i                                                        integrate_terms
+// M = reference-element mass matrix of the level.  One pass of the FUSED operator apply in "reductions only" form
+// (no output vector): mass term only and unscaled, unit multiplicities, no constraint; the per-cell sum it leaves
+// in blockpart is sum_i x_i (src_i + (M x)_i) resp. sum_i (x_i + src_i) (M x)_i, scaled by |J_c| in the reduction.
+// Works for every level the apply works for (the slab kernel included) and moves 16 B per DOF.
 // ---------------------------------------------------------------------------------------------
-template <int DIM>
-__global__ void __launch_bounds__(256)
-k_integrate(LevelDev lv, const double *__restrict__ coef, int mode, const double *__restrict__ v,
-            const double *__restrict__ w2, const double *__restrict__ pvec, double *blockpart)
-{
-    constexpr int NDIR = DIM == 3 ? 15 : 7;
-    constexpr int NTERM = DIM == 3 ? 7 : 4;
-    constexpr int NT = 256;
-    extern __shared__ double smem[];
-    double *W = smem;
-    double *xs = smem + WSZ + lv.lds_g0;
-    const int tid = threadIdx.x;
-    const int64_t cell = blockIdx.x;
-    const int nf = lv.nf;
-    for (int idx = tid; idx < lv.ncls * NDIR; idx += NT) W[idx] = lv.ctab[(size_t)idx * NTERM + NTERM - 1];
-    for (int q = tid; q < lv.lds_g0; q += NT) smem[WSZ + q] = 0.0;
-    for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
-    const double *vc = v + cell * lv.ld;
-    for (int t = tid; t < nf; t += NT) xs[lv.lpos[t]] = vc[t];
-    __syncthreads();
-    const double *wc = w2 ? w2 + cell * lv.ld : nullptr;
-    double p0 = 0.0, p1 = 0.0, p2 = 0.0;
-    if (mode == 0) {
-        p0 = pvec[3 * cell];
-        p1 = pvec[3 * cell + 1];
-        p2 = pvec[3 * cell + 2];
-    }
-    double acc = 0.0;
-    for (int t = tid; t < nf; t += NT) {
-        int L, len, A, B, cls;
-        decode32<DIM>(lv.pos32[t], lv.m, L, len, A, B, cls);
-        double ctr;
-        const double mv = stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
-        if (mode == 0) {
-            const double *d = lv.dphi + 3 * t;
-            double dp = d[0] * p0;
-            dp += d[1] * p1;
-            if (DIM == 3) dp += d[2] * p2;
-            acc += ctr * (dp + mv);
-        } else
-            acc += (ctr + wc[t]) * mv;
-    }
-    __syncthreads();
-    const double s = block_sum(acc, smem);
-    if (tid == 0) {
-        blockpart[2 * cell] = s * coef[cell * 8 + NTERM - 1];   // times |J|
-        blockpart[2 * cell + 1] = 0.0;
-    }
-}
-
 void launch_integrate(const Launch &L, const LevelDev &lv, const MeshDev &mesh, int mode, int64_t nsub, const double *v,
-                      const double *w2, const double *pvec, int slot)
+                      const double *second, int slot)
 {
-    const size_t lds = apply_lds_bytes(lv);
-    if (lds > 160 * 1024) throw std::runtime_error("integrals: cell does not fit LDS");
-    if (lv.dim == 3) {
-        auto k = k_integrate<3>;
-        if (lds > 48 * 1024)
-            HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)nsub), dim3(256), lds, L.stream, lv, mesh.coef, mode, v, w2, pvec,
-                           mesh.blockpart);
-    } else {
-        auto k = k_integrate<2>;
-        if (lds > 48 * 1024)
-            HMG_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)nsub), dim3(256), lds, L.stream, lv, mesh.coef, mode, v, w2, pvec,
-                           mesh.blockpart);
-    }
-    check_launch();
-    hipLaunchKernelGGL(k_reduce_pairs, dim3(256), dim3(256), 0, L.stream, mesh.blockpart, nsub, L.partials);
+    ApplyArgs a{};
+    a.alpha = 1.0;
+    a.lambda = 1.0;
+    a.x = v;
+    a.src = second;
+    a.flags = 2 | 16 | 32 | (mode == 1 ? 8 : 0);
+    a.ncells_prefix = nsub;
+    launch_apply_fused_kernel(L, lv, mesh, a);
+    hipLaunchKernelGGL(k_reduce_weighted, dim3(256), dim3(256), 0, L.stream, mesh.blockpart, mesh.coef, lv.nterm - 1, nsub,
+                       L.partials);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, 256, L.scal, slot);
     check_launch();
 }

@@ -62,14 +62,15 @@ __device__ __forceinline__ double sum_partials_all(const double *__restrict__ pa
 
 // Per-cell scale of every operator term: alpha*|J|*P_kl for the diffusion terms, alpha*lambda*|J| for the
 // mass term; mass_only (next_rhs!) zeroes the diffusion part.
+// flags bit 1: mass term only; bit 4: ... and not scaled by |J| (the driver integrals scale the per-cell sums instead)
 template <int DIM>
 __device__ __forceinline__ void cell_scales(const double *__restrict__ cc, double alpha, double lambda, double *s,
-                                            int mass_only = 0)
+                                            int flags = 0)
 {
     constexpr int NTERM = DIM == 3 ? 7 : 4;
 #pragma unroll
-    for (int t = 0; t < NTERM - 1; ++t) s[t] = mass_only ? 0.0 : alpha * cc[t];
-    s[NTERM - 1] = alpha * lambda * cc[NTERM - 1];
+    for (int t = 0; t < NTERM - 1; ++t) s[t] = (flags & 2) ? 0.0 : alpha * cc[t];
+    s[NTERM - 1] = alpha * lambda * ((flags & 16) ? 1.0 : cc[NTERM - 1]);
 }
 
 // LDS read that the backend must not fuse into ds_read2_b64 (8 LDS cycles for 2x8 B per lane, half
@@ -203,8 +204,10 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 template <uint32_t M, int NITEM, bool FUSED>
 __device__ __forceinline__ void class_items(double wv, int wlane0, const double *xs, int m, int nfi, int slot_base, int t0,
                                             const uint32_t (&fw)[NITEM], bool dirichlet, double mult, const double *sc,
-                                            double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre)
+                                            double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre,
+                                            bool wdot = false)
 {
+    // wdot: the source value multiplies instead of being added: out = alpha A x, pap += mult (x + src) out
     // wv: the class weight row, spread over the lanes wlane0 .. wlane0 + 14 of this wave; M: the taps that exist
     double w[15];
 #pragma unroll
@@ -237,8 +240,8 @@ __device__ __forceinline__ void class_items(double wv, int wlane0, const double 
                 if ((M >> 12) & 1u) acc += w[12] * lds_ld(pd);
                 if ((M >> 13) & 1u) acc += w[13] * lds_ld(pu + 1 - len);
                 if ((M >> 14) & 1u) acc += w[14] * lds_ld(pd + len);
-                o = sv + acc;
-                if (FUSED) pap += mult * (ctr * o);
+                o = wdot ? acc : sv + acc;
+                if (FUSED) pap += mult * ((wdot ? ctr + sv : ctr) * o);
             }
             if (!FUSED || oc) oc[t] = o;
         }
@@ -248,10 +251,11 @@ __device__ __forceinline__ void class_items(double wv, int wlane0, const double 
 template <int F, int NITEM, bool FUSED>
 __device__ __forceinline__ void face_items(double wv, int wlane0, const double *xs, int m, int nfi, int slot_base, int t0,
                                            const uint32_t (&fw)[NITEM], bool dirichlet, double mult, const double *sc,
-                                           double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre)
+                                           double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre,
+                                           bool wdot = false)
 {
     class_items<face_tap_mask(F), NITEM, FUSED>(wv, wlane0, xs, m, nfi, slot_base, t0, fw, dirichlet, mult, sc, oc, pap, lane,
-                                                pre, use_pre);
+                                                pre, use_pre, wdot);
 }
 
 // Edge e of the reference simplex lies on two faces (edge order of the reference: (1,2) (1,3) (1,4) (2,3) (2,4) (3,4) =
@@ -287,9 +291,11 @@ __device__ __forceinline__ void block_slots(int m, uint32_t word, int slot0, int
 }
 
 // acc[r] holds the value the sum of node r starts from (0, or the source value for out = src + alpha A x).
-template <int R, bool FUSED>
+// WDOT: wsv[r] is added to the node's own value in the p.Ap-type sum (driver integrals: (v + w) . M v).
+template <int R, bool FUSED, bool WDOT = false>
 __device__ __forceinline__ void interior_block_core(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
-                                                    int slot0, double *oc, double &pap, double (&acc)[R])
+                                                    int slot0, double *oc, double &pap, double (&acc)[R],
+                                                    const double *wsv = nullptr)
 {
     const int L = (int)(word & 0xffffu), j = (int)((word >> 16) & 63u), k0 = (int)((word >> 22) & 63u);
     const int nv = (int)(word >> 28);
@@ -324,7 +330,7 @@ __device__ __forceinline__ void interior_block_core(const double (&w)[15], const
             t += w[11] * v3;
             if (s - 2 < nv) {
                 if (!FUSED || oc) oc[slot] = t;
-                if (FUSED) pap += ctr[s - 2] * t;   // (meaningful for the CG passes, which have no src)
+                if (FUSED) pap += (WDOT ? ctr[s - 2] + wsv[s - 2] : ctr[s - 2]) * t;   // (the CG passes have no src)
             }
             slot += ds;
             ds -= n0 - s;                   // n0 - 2 - r, r = s - 2
@@ -361,7 +367,7 @@ __device__ __forceinline__ void interior_block_core(const double (&w)[15], const
 // SRC: out = src + alpha A x -- the R source values are loaded first (their global latency hides behind the planes).
 template <int R, bool FUSED, bool SRC>
 __device__ __forceinline__ void interior_block(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
-                                               int slot0, const double *sc, double *oc, double &pap)
+                                               int slot0, const double *sc, double *oc, double &pap, bool wdot = false)
 {
     double acc[R];
     if (SRC) {
@@ -370,6 +376,16 @@ __device__ __forceinline__ void interior_block(const double (&w)[15], const doub
         const int nv = (int)(word >> 28);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = r < nv ? sc[slot[r]] : 0.0;
+        if (FUSED && wdot) {                 // the source values multiply (see class_items)
+            double wsv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                wsv[r] = acc[r];
+                acc[r] = 0.0;
+            }
+            interior_block_core<R, FUSED, true>(w, xs, m, safe, word, slot0, oc, pap, acc, wsv);
+            return;
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.0;

@@ -263,7 +263,7 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
             nint = grid.local_count_below(driver.find_elements_in_radius(cur, box_radius))
             area = api.integrate_area(top.x, grid, nint)
             if k == 0:
-                integral = api.integrate_first_term(top.x, grid, nint, xi)
+                integral = api.integrate_first_term(top.x, grid, nint, xi, b=top.b)
             else:
                 integral = api.integrate_terms(top.x, v_prev, grid, nint)
             area, integral = rank_sum(area, integral)

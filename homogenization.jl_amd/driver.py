@@ -199,7 +199,7 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
             nint = find_elements_in_radius(cur, box_radius)
             area = api.integrate_area(top.x, implicit, nint)
             if k == 0:
-                integral = api.integrate_first_term(top.x, implicit, nint, xi)
+                integral = api.integrate_first_term(top.x, implicit, nint, xi, b=top.b)   # b = rhs_a.xi.grad(v) at k = 0
             else:
                 integral = api.integrate_terms(top.x, v_prev, implicit, nint)
             dsig = 2.0 ** k * integral / area

@@ -124,10 +124,12 @@ int hmg_rhs_axi_grad(hmg_grid *grid, const double *xi /* dim */, hmg_vec *b);
 /* local_rhs!(b, implicit): b[:, e] = |det J_e| * int phi over the refined reference cell (unit load;
  * src/implicit_fine_grid.jl:391-409, used by checkerboard_hypercube_multigrid, ...homogenized_coefficients.jl:543) */
 int hmg_local_rhs(hmg_grid *grid, hmg_vec *b);
-/* integrate_first_term (mode 0, needs xi), integrate_terms (mode 1, needs vprev), integrate_area (mode 2) over
- * the first ncells_subset cells   (src/examples/homogenized_coefficients.jl:592-689).  Partitioned grid: local
- * cells, this rank's share of the integral (the host adds the shares). */
-int hmg_integrate(hmg_grid *grid, int mode, hmg_vec *v, hmg_vec *vprev, int64_t ncells_subset, const double *xi,
+/* integrate_first_term (mode 0), integrate_terms (mode 1), integrate_area (mode 2) over the first ncells_subset cells
+ * (src/examples/homogenized_coefficients.jl:592-689).  `second` is, for mode 0, the vector rhs_a xi grad v! produced for
+ * the same xi (hmg_rhs_axi_grad: the reference recomputes dot(dphi_i, P) per node, :621 -- it is that vector entry);
+ * for mode 1 the previous iterate v_{k-1}.  One 16 B/DOF pass of the operator-apply kernel in reductions-only form, on
+ * every level the apply supports.  Partitioned grid: local cells, this rank's share (the host adds the shares). */
+int hmg_integrate(hmg_grid *grid, int mode, hmg_vec *v, hmg_vec *second, int64_t ncells_subset, const double *xi,
                   double *out);
 /* next_rhs!(b, x, implicit, ops): b = lambda*|J|*M*x  (src/examples/homogenized_coefficients.jl:695-713) */
 int hmg_next_rhs(hmg_grid *grid, hmg_vec *x, hmg_vec *b);

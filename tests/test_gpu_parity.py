@@ -392,9 +392,12 @@ def test_driver_integrals(case3):
     dphis = O.partial_derivatives_functionals(c.impl.reference.levels[-1])
     v, w = c.rand(lev), c.rand(lev)
     dv, dw = c.dev(lev, v), c.dev(lev, w)
+    db = hmg.DeviceMatrix(c.g, lev)
+    hmg.rhs_axi_grad_v(db, c.g, xi)                                    # dot(dphi_i, P): the first term's linear part
     for nsub in (0, 7, c.mesh.nelements()):
         a = O.integrate_first_term(v, dphis, c.impl, nsub, mass, c.sig, xi)
-        assert abs(hmg.integrate_first_term(dv, c.g, nsub, xi) - a) <= 1e-11 * max(abs(a), 1.0)
+        assert abs(hmg.integrate_first_term(dv, c.g, nsub, xi, b=db) - a) <= 1e-11 * max(abs(a), 1.0)
+        assert abs(hmg.integrate_first_term(dv, c.g, nsub, xi) - a) <= 1e-11 * max(abs(a), 1.0)   # temporary b
         b = O.integrate_terms(v, w, c.impl, nsub, mass)
         assert abs(hmg.integrate_terms(dv, dw, c.g, nsub) - b) <= 1e-11 * max(abs(b), 1.0)
         ar = O.integrate_area(mass, c.impl, nsub)

@@ -231,6 +231,54 @@ def test_l6_vcycle(case6):
         assert relerr(dsts[-1].p.to_host(), sts[-1].p) <= 1e-8, cyc
 
 
+@pytest.mark.parametrize("which", ["l6", "l7"])
+def test_driver_integrals_large_levels(oracle, ctx, case6, which):
+    """integrate_first_term / integrate_terms on the levels of BASELINE configs 3 and 5 (level 6: register-blocked kernel;
+    level 7: slab kernel -- round 1 threw "cell does not fit LDS" here).  ref: ...homogenized_coefficients.jl:592-667"""
+    O = oracle
+    c = case6 if which == "l6" else Case(O, ctx, 3, 1, 7, lam=0.9, perturb=0.1, seed=13, ordered=False)
+    lev = c.levels
+    xi = np.array([0.2, -0.5, 0.84])
+    mass = O.mass_matrix(c.impl.reference.levels[-1])
+    dphis = O.partial_derivatives_functionals(c.impl.reference.levels[-1])
+    v, w = c.rand(lev), c.rand(lev)
+    dv, dw = c.dev(lev, v), c.dev(lev, w)
+    db = hmg.DeviceMatrix(c.g, lev)
+    hmg.rhs_axi_grad_v(db, c.g, xi)
+    for nsub in (1, c.mesh.nelements()):
+        a = O.integrate_first_term(v, dphis, c.impl, nsub, mass, c.sig, xi)
+        assert abs(hmg.integrate_first_term(dv, c.g, nsub, xi, b=db) - a) <= 1e-11 * max(abs(a), 1.0)
+        b = O.integrate_terms(v, w, c.impl, nsub, mass)
+        assert abs(hmg.integrate_terms(dv, dw, c.g, nsub) - b) <= 1e-11 * max(abs(b), 1.0)
+    x = c.rand(lev)                                                     # next_rhs! on the same levels
+    want = np.zeros_like(x, order="F")
+    O.next_rhs(want, x, c.impl, mass, c.lam)
+    hmg.next_rhs(db, c.dev(lev, x), c.g)
+    assert relerr(db.to_host(), want) <= 1e-12
+
+
+def test_checkerboard_homogenization_refinements_6(oracle, ctx):
+    """The driver at the upper end of the north-star range, refinements = 6 (7 levels, Nf = 47 905): n = 0 (width 10,
+    6000 cells, one outer step without a shrink... the outer loop ends when the domain would grow) against the oracle
+    driver on identical sigma and x0: |delta sigma| <= 1e-8, same number of V-cycles.  ref: ...:174-343"""
+    from homogenization_jl_amd import driver
+    O = oracle
+    n, refinements, tol = 0, 6, 1e-2
+    width = 2 * (driver.compute_box_radius(0, n) + driver.compute_boundary_layer(1.0, n))
+    sgrid = driver.generate_conductivity(3, width, 11)
+    ne = 6 * width ** 3
+    x0 = hmg.host_random((47905, ne), 99)
+    want, hist_o = O.checkerboard_homogenization(n=n, dim=3, refinements=refinements, tolerance=tol, sigma_grid=sgrid, x0=x0)
+    got, hist_d = driver.checkerboard_homogenization(n, hmg.Tet64, refinements=refinements, tolerance=tol, ctx=ctx,
+                                                     sigma_grid=sgrid, x0=x0)
+    assert len(hist_o) == len(hist_d)
+    assert abs(got - want) <= 1e-8
+    for a, b in zip(hist_o, hist_d):
+        assert a[:2] == b[:2]
+        assert abs(a[2] - b[2]) <= 1e-7 * max(a[2], 1e-12)
+        assert abs(a[3] - b[3]) <= 1e-8
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BASELINE config 5: high contrast, refinements = 6
 # ---------------------------------------------------------------------------------------------------------------
