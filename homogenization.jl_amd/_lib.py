@@ -82,6 +82,13 @@ SIGNATURES = {
     "hmg_grid_set_exchange_async": (c_int, [vp, EXCHANGE_FN, EXCHANGE_END_FN]),
     "hmg_grid_set_overlap": (c_int, [vp, c_int]),
     "hmg_ctx_set_scalar_bank": (c_int, [vp, vp]),
+    "hmg_ctx_stream": (vp, [vp]),
+    "hmg_comm_unique_id": (c_int, [vp]),
+    "hmg_comm_init": (c_int, [vp, c_int, c_int, vp]),
+    "hmg_comm_destroy": (c_int, [vp]),
+    "hmg_comm_stats": (c_int, [vp, p_i64, p_i64]),
+    "hmg_comm_sum_host": (c_int, [vp, p_f64, c_int]),
+    "hmg_grid_use_comm": (c_int, [vp]),
     "hmg_grid_create_partition": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, p_i32, c_int, c_int, pp]),
 }
 

@@ -20,6 +20,7 @@ hierarchical layout.  There is no CPU implementation behind these calls.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -59,6 +60,35 @@ class Context:
             L.check(self._lib.hmg_ctx_create_on_stream(device, ctypes.c_void_p(int(stream)), ctypes.byref(h)))
         self.h = h
         self.device = device
+        self._keepalive = []      # caller-side memory the library points into (e.g. a scalar bank tensor)
+        self._fin = weakref.finalize(self, self._lib.hmg_ctx_destroy, h)
+
+    def stream_handle(self) -> int:
+        """The context's hipStream_t as an integer (0 = the null stream): foreign collectives must be issued on it."""
+        return int(self._lib.hmg_ctx_stream(self.h) or 0)
+
+    # -- in-library communicator (RCCL), see include/hmg.h ---------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        L.check(L.load().hmg_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        L.check(self._lib.hmg_comm_init(self.h, nranks, rank, ctypes.c_char_p(unique_id)))
+
+    def comm_stats(self):
+        n = ctypes.c_int64()
+        d = ctypes.c_int64()
+        L.check(self._lib.hmg_comm_stats(self.h, ctypes.byref(n), ctypes.byref(d)))
+        return n.value, d.value
+
+    def comm_sum_host(self, *vals):
+        """Sum of a few host doubles over the ranks of the in-library communicator (blocking)."""
+        a = np.array(vals, dtype=np.float64)
+        L.check(self._lib.hmg_comm_sum_host(self.h, a.ctypes.data_as(L.p_f64), a.size))
+        return [float(v) for v in a]
 
     def sync(self):
         L.check(self._lib.hmg_ctx_sync(self.h))
@@ -80,7 +110,7 @@ class Context:
 
     def close(self):
         if self.h:
-            self._lib.hmg_ctx_destroy(self.h)
+            self._fin()           # hmg_ctx_destroy, once
             self.h = None
 
 
@@ -100,6 +130,7 @@ class ImplicitFineGrid:
                                           nodes.ctypes.data_as(L.p_f64), cells.shape[0],
                                           cells.ctypes.data_as(L.p_i64), ctypes.byref(h)))
         self.h = h
+        self._fin = weakref.finalize(self, self._lib.hmg_grid_destroy, h)   # (vectors keep the grid alive, the grid the ctx)
 
     # -- queries -----------------------------------------------------------------------------
     def nlevels(self):
@@ -154,7 +185,7 @@ class ImplicitFineGrid:
 
     def close(self):
         if self.h:
-            self._lib.hmg_grid_destroy(self.h)
+            self._fin()
             self.h = None
 
 
@@ -171,6 +202,9 @@ class DeviceMatrix:
         else:
             L.check(self._lib.hmg_vec_wrap(implicit.h, level, ctypes.c_void_p(device_ptr), ctypes.byref(h)))
         self.h = h
+        # HBM goes back when the object is collected (or close()d); `implicit` is referenced above, so the grid and its
+        # context outlive every vector
+        self._fin = weakref.finalize(self, self._lib.hmg_vec_destroy, h)
 
     @property
     def shape(self):
@@ -210,7 +244,7 @@ class DeviceMatrix:
 
     def close(self):
         if self.h:
-            self._lib.hmg_vec_destroy(self.h)
+            self._fin()
             self.h = None
 
 
@@ -314,6 +348,10 @@ class LevelState:
 
     def handles(self):
         return [self.x.h, self.b.h, self.r.h, self.p.h, self.Ap.h]
+
+    def close(self):
+        for v in (self.x, self.b, self.r, self.p, self.Ap):
+            v.close()
 
 
 def mul(alpha, implicit: ImplicitFineGrid, A, x: DeviceMatrix, y: DeviceMatrix):

@@ -4,6 +4,9 @@
 #include "hmg_device.hpp"
 #include "hmg_host.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -106,6 +109,12 @@ struct hmg_ctx {
     int coarse_maxit = 5000;
     int coarse_check = 25;
     double coarse_rtol = 1e-13;
+    // in-library communicator (one rank per GPU, RCCL over xGMI): hmg_comm_init
+    ncclComm_t comm = nullptr;
+    int comm_nranks = 1, comm_rank = 0;
+    hipStream_t comm_stream = nullptr;       // the overlapped cut exchange runs here
+    hipEvent_t ev_packed = nullptr, ev_summed = nullptr;
+    int64_t comm_calls = 0, comm_doubles = 0;
 };
 
 struct hmg_grid {
@@ -151,6 +160,7 @@ struct hmg_grid {
     void *ex_user = nullptr;
     double *ex_buf = nullptr;
     int64_t ex_cap = 0;
+    DevBuf<double> own_exbuf;                    // hmg_grid_use_comm: library-owned exchange buffer
 
     const MeshTables &cur() const { return shrunk ? mesh : mesh_full; }
 };
@@ -720,8 +730,13 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     auto sums = [&]() {
         if (!fused || slot_pap < 0) return;
         launch_apply_fused_reduce(L, g->md, slot_pap, slot_rr);
-        if (slot_rr >= 0) scalar_sum(g, slot_rr, 1);
-        scalar_sum(g, slot_pap, 1);
+        // (r.r and p.Ap of CG step 0 sit in neighbouring slots of the scalar bank: one sum over ranks for both)
+        if (slot_rr >= 0 && (slot_rr == slot_pap + 1 || slot_rr + 1 == slot_pap))
+            scalar_sum(g, std::min(slot_rr, slot_pap), 2);
+        else {
+            if (slot_rr >= 0) scalar_sum(g, slot_rr, 1);
+            scalar_sum(g, slot_pap, 1);
+        }
     };
     if (!a.out) {                    // reductions only (dead-tail step of a pre-smoother): nothing to sum or exchange
         need(fused, "apply without an output vector");
@@ -1112,6 +1127,100 @@ void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x)
 
 }  // namespace
 
+// ---- in-library communicator: RCCL, resolved at run time ------------------------------------------
+// librccl is opened with dlopen when a communicator is first asked for (a host process that already holds a copy --
+// torch bundles one -- shares it), so the library loads and runs single-GPU without RCCL present.
+namespace {
+
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi &rccl()
+{
+    static RcclApi api;
+    if (api.h) return api;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+        if ((api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!api.h)
+        for (const char *n : names)
+            if ((api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!api.h) throw std::runtime_error(std::string("RCCL not found (dlopen librccl.so.1): ") + dlerror());
+    auto sym = [&](const char *n) {
+        void *p = dlsym(api.h, n);
+        if (!p) throw std::runtime_error(std::string("RCCL symbol missing: ") + n);
+        return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    return api;
+}
+
+void nccl_check(ncclResult_t r, const char *what)
+{
+    if (r != ncclSuccess) throw std::runtime_error(std::string("RCCL error in ") + what + ": " + rccl().GetErrorString(r));
+}
+
+// in-place sum over ranks of n doubles, enqueued on `s`
+void comm_allreduce(hmg_ctx *c, double *buf, int64_t n, hipStream_t s)
+{
+    nccl_check(rccl().AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c->comm, s), "ncclAllReduce");
+    c->comm_calls += 1;
+    c->comm_doubles += n;
+}
+
+// the built-in forms of the exchange callbacks (user = the grid): everything is enqueued on HIP streams, no host
+// synchronisation and no foreign code between two kernels of a V-cycle
+int comm_exchange(void *user, void *buf, int64_t n)
+{
+    hmg_grid *g = (hmg_grid *)user;
+    try {
+        comm_allreduce(g->ctx, (double *)buf, n, g->ctx->stream);
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return 1;
+    }
+    return 0;
+}
+
+int comm_exchange_begin(void *user, void *buf, int64_t n)
+{
+    hmg_grid *g = (hmg_grid *)user;
+    hmg_ctx *c = g->ctx;
+    try {
+        HIPCHK(hipEventRecord(c->ev_packed, c->stream));             // the pack kernels
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+        comm_allreduce(c, (double *)buf, n, c->comm_stream);
+        HIPCHK(hipEventRecord(c->ev_summed, c->comm_stream));
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return 1;
+    }
+    return 0;
+}
+
+int comm_exchange_end(void *user)
+{
+    hmg_grid *g = (hmg_grid *)user;
+    hipError_t e = hipStreamWaitEvent(g->ctx->stream, g->ctx->ev_summed, 0);
+    if (e != hipSuccess) {
+        last_error() = std::string("HIP error: ") + hipGetErrorString(e);
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
 // =============================================================================================
 static double read_scalar(hmg_ctx *c, int slot);
 
@@ -1172,6 +1281,10 @@ int hmg_ctx_destroy(hmg_ctx *ctx)
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
+        if (ctx->comm) (void)rccl().CommDestroy(ctx->comm);
+        if (ctx->ev_packed) (void)hipEventDestroy(ctx->ev_packed);
+        if (ctx->ev_summed) (void)hipEventDestroy(ctx->ev_summed);
+        if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
     }
@@ -1243,10 +1356,11 @@ void *hmg_ctx_scalar_bank(hmg_ctx *ctx) { return ctx ? (void *)ctx->L.scal : nul
 int hmg_ctx_set_scalar_bank(hmg_ctx *ctx, void *device_doubles16)
 {
     HMG_TRY
-    need(ctx && device_doubles16, "null argument");
+    need(ctx != nullptr, "null argument");
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpy(device_doubles16, ctx->L.scal, S_COUNT * sizeof(double), hipMemcpyDeviceToDevice));
-    ctx->L.scal = (double *)device_doubles16;
+    double *to = device_doubles16 ? (double *)device_doubles16 : ctx->scal.p;   // NULL: back to the library's own bank
+    if (to != ctx->L.scal) HIPCHK(hipMemcpy(to, ctx->L.scal, S_COUNT * sizeof(double), hipMemcpyDeviceToDevice));
+    ctx->L.scal = to;
     HMG_END
 }
 
@@ -2041,6 +2155,93 @@ int hmg_grid_set_overlap(hmg_grid *g, int enabled)
     g->overlap = enabled != 0;
     HMG_END
 }
+
+int hmg_comm_unique_id(void *out128)
+{
+    HMG_TRY
+    need(out128 != nullptr, "null argument");
+    ncclUniqueId id;
+    nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    static_assert(sizeof(id) == HMG_COMM_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(out128, &id, sizeof(id));
+    HMG_END
+}
+
+int hmg_comm_init(hmg_ctx *ctx, int nranks, int rank, const void *unique_id128)
+{
+    HMG_TRY
+    need(ctx && unique_id128, "null argument");
+    need(nranks >= 1 && rank >= 0 && rank < nranks, "rank out of range");
+    need(ctx->comm == nullptr, "this context already has a communicator");
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id128, sizeof(id));
+    nccl_check(rccl().CommInitRank(&ctx->comm, nranks, id, rank), "ncclCommInitRank");
+    ctx->comm_nranks = nranks;
+    ctx->comm_rank = rank;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_packed, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_summed, hipEventDisableTiming));
+    HMG_END
+}
+
+int hmg_comm_destroy(hmg_ctx *ctx)
+{
+    HMG_TRY
+    need(ctx != nullptr, "null ctx");
+    if (ctx->comm) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->comm_stream));
+        nccl_check(rccl().CommDestroy(ctx->comm), "ncclCommDestroy");
+        ctx->comm = nullptr;
+    }
+    HMG_END
+}
+
+int hmg_comm_stats(hmg_ctx *ctx, int64_t *calls, int64_t *doubles)
+{
+    HMG_TRY
+    need(ctx && calls && doubles, "null argument");
+    *calls = ctx->comm_calls;
+    *doubles = ctx->comm_doubles;
+    HMG_END
+}
+
+int hmg_comm_sum_host(hmg_ctx *ctx, double *vals, int count)
+{
+    HMG_TRY
+    need(ctx && vals, "null argument");
+    need(ctx->comm != nullptr, "hmg_comm_init must be called first");
+    need(count >= 1 && count <= 7, "count must be 1..7");
+    double *d = ctx->L.scal + 9;     // (slots 9..15 of the scalar bank are not used by the kernels)
+    HIPCHK(hipMemcpyAsync(d, vals, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+    comm_allreduce(ctx, d, count, ctx->stream);
+    HIPCHK(hipMemcpyAsync(vals, d, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HMG_END
+}
+
+int hmg_grid_use_comm(hmg_grid *g)
+{
+    HMG_TRY
+    need(g && g->ctx, "null grid or host-only grid");
+    need(g->ctx->comm != nullptr, "hmg_comm_init must be called on the grid's context first");
+    need(g->part != nullptr, "not a partitioned grid (hmg_grid_create_partition)");
+    need(g->part->nranks == g->ctx->comm_nranks && g->part->rank == g->ctx->comm_rank,
+         "the grid's partition and the context's communicator disagree on rank / size");
+    const int64_t cap = std::max<int64_t>(hmg_grid_cut_buffer_doubles(g, 0), 1);
+    g->own_exbuf.alloc((size_t)cap);
+    g->ex_buf = g->own_exbuf.p;
+    g->ex_cap = cap;
+    g->ex_user = g;
+    g->exchange = comm_exchange;
+    g->scalar_sum = comm_exchange;           // (the same in-place sum, on the scalar bank)
+    g->ex_begin = comm_exchange_begin;
+    g->ex_end = comm_exchange_end;
+    HMG_END
+}
+
+void *hmg_ctx_stream(hmg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *g, int level)
 {

@@ -79,27 +79,51 @@ class PartitionedGrid(api.ImplicitFineGrid):
 
 
 class Exchange:
-    """Sum-over-ranks callbacks for one grid, on torch.distributed."""
+    """The sum over ranks behind one partitioned grid.
 
-    def __init__(self, ctx: api.Context, grid: PartitionedGrid, group=None):
+    backend "rccl" (default whenever the process group is NCCL = RCCL): the library's own communicator
+    (hmg_comm_init / hmg_grid_use_comm, include/hmg.h) -- ncclAllReduce on the context's HIP streams, no Python between
+    two kernels of a V-cycle; torch.distributed is used once, to hand rank 0's unique id to the other ranks.
+    backend "torch": callbacks into torch.distributed (any backend that reduces device tensors, e.g. gloo for
+    single-GPU rehearsals); the collectives are issued on the CONTEXT's stream, whatever torch's current stream is."""
+
+    def __init__(self, ctx: api.Context, grid: PartitionedGrid, group=None, backend: str | None = None):
         import torch
         import torch.distributed as dist
-        self.dist, self.group = dist, group
-        dev = torch.device("cuda", ctx.device)
-        n = max(grid.exchange_doubles(), 1)
-        self.buf = torch.zeros(n, dtype=torch.float64, device=dev)
-        self.scal = torch.zeros(16, dtype=torch.float64, device=dev)
-        lib = L.load()
-        L.check(lib.hmg_ctx_set_scalar_bank(ctx.h, ctypes.c_void_p(self.scal.data_ptr())))
+        self.dist, self.group, self.ctx = dist, group, ctx
+        if backend is None:
+            backend = "rccl" if dist.is_initialized() and dist.get_backend(group) == "nccl" else "torch"
+        self.backend = backend
         self.calls = 0
         self.seconds = 0.0          # host time spent inside the collectives (blocking backends only, e.g. gloo)
         self.doubles = 0
+        dev = torch.device("cuda", ctx.device)
+        lib = L.load()
+        if backend == "rccl":
+            if not getattr(ctx, "_comm_ready", False):
+                uid = [api.Context.comm_unique_id() if grid.rank == 0 else None]
+                if grid.nranks > 1:
+                    dist.broadcast_object_list(uid, src=0, group=group)
+                ctx.comm_init(grid.nranks, grid.rank, uid[0])
+                ctx._comm_ready = True
+            L.check(lib.hmg_grid_use_comm(grid.h))
+            grid._exchange = self
+            return
+        n = max(grid.exchange_doubles(), 1)
+        self.buf = torch.zeros(n, dtype=torch.float64, device=dev)
+        self.scal = torch.zeros(16, dtype=torch.float64, device=dev)
+        # the context outlives every grid: it keeps the memory the library now points into
+        ctx._keepalive += [self.buf, self.scal]
+        L.check(lib.hmg_ctx_set_scalar_bank(ctx.h, ctypes.c_void_p(self.scal.data_ptr())))
         import time as _time
+        sh = ctx.stream_handle()
+        self._stream = torch.cuda.ExternalStream(sh, device=dev) if sh else torch.cuda.default_stream(dev)
 
         def _sum(tensor, ptr, count):
             off = (ptr - tensor.data_ptr()) // 8
             t0 = _time.perf_counter()
-            self.dist.all_reduce(tensor[off:off + count], group=self.group)
+            with torch.cuda.stream(self._stream):      # behind the pack kernels, before the unpack kernels
+                self.dist.all_reduce(tensor[off:off + count], group=self.group)
             self.seconds += _time.perf_counter() - t0
             self.calls += 1
             self.doubles += count
@@ -125,7 +149,8 @@ class Exchange:
             try:
                 off = (ptr - self.buf.data_ptr()) // 8
                 t0 = _time.perf_counter()
-                self._work = self.dist.all_reduce(self.buf[off:off + count], group=self.group, async_op=True)
+                with torch.cuda.stream(self._stream):
+                    self._work = self.dist.all_reduce(self.buf[off:off + count], group=self.group, async_op=True)
                 self.seconds += _time.perf_counter() - t0
                 self.calls += 1
                 self.doubles += count
@@ -138,7 +163,8 @@ class Exchange:
             try:
                 if self._work is not None:
                     t0 = _time.perf_counter()
-                    self._work.wait()          # NCCL: the current stream waits; gloo: the host waits
+                    with torch.cuda.stream(self._stream):
+                        self._work.wait()          # NCCL: the context's stream waits; gloo: the host waits
                     self.seconds += _time.perf_counter() - t0
                     self._work = None
                 return 0
@@ -147,7 +173,8 @@ class Exchange:
                 return 1
 
         self._cb = (L.EXCHANGE_FN(_exchange), L.EXCHANGE_FN(_scalar), L.EXCHANGE_FN(_begin),
-                    L.EXCHANGE_END_FN(_end))                                # keep alive
+                    L.EXCHANGE_END_FN(_end))
+        ctx._keepalive.append(self._cb)                                     # the grid calls them as long as it lives
         L.check(lib.hmg_grid_set_exchange(grid.h, self._cb[0], self._cb[1], None,
                                           ctypes.c_void_p(self.buf.data_ptr()), n))
         L.check(lib.hmg_grid_set_exchange_async(grid.h, self._cb[2], self._cb[3]))
@@ -155,6 +182,21 @@ class Exchange:
 
     def set_overlap(self, grid, enabled: bool):
         L.check(L.load().hmg_grid_set_overlap(grid.h, 1 if enabled else 0))
+
+    def stats(self):
+        """(collectives, doubles moved) so far."""
+        if self.backend == "rccl":
+            return self.ctx.comm_stats()
+        return self.calls, self.doubles
+
+    def rank_sum(self, *vals):
+        """Sum of a few host doubles over the ranks (the driver's per-cycle integrals)."""
+        if self.backend == "rccl":
+            return self.ctx.comm_sum_host(*vals)
+        import torch
+        t = torch.tensor(vals, dtype=torch.float64, device=torch.device("cuda", self.ctx.device))
+        self.dist.all_reduce(t, group=self.group)
+        return [float(v) for v in t.tolist()]
 
 
 def block_shape(world: int, dim: int = 3):
@@ -186,7 +228,7 @@ class PartitionedProblem:
 
 
 def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int, seed: int = 0, values=(1.0, 9.0),
-                             lam: float = 1.0, group=None):
+                             lam: float = 1.0, group=None, backend=None):
     """Weak-scaling checkerboard: a brick of `world` blocks of width^3 unit cubes, one block per rank."""
     blocks = block_shape(world, 3)
     shape = tuple(width * b for b in blocks)
@@ -197,7 +239,7 @@ def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int
     cond = driver.conductivity_per_element(base, sgrid, tuple(1.0 - o for o in origin))
     owner = block_owner(base, blocks, width, origin)
     grid = PartitionedGrid(ctx, base, levels, owner, rank, world)
-    ex = Exchange(ctx, grid, group)
+    ex = Exchange(ctx, grid, group, backend)
     op = api.L2PlusDivAGrad(grid, lam, cond)
     p = PartitionedProblem()
     p.base, p.cond, p.implicit, p.op, p.exchange = grid.base, cond, grid, op, ex
@@ -210,15 +252,18 @@ def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int
 def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, rank: int, refinements: int = 2,
                                             smoothing_steps: int = 3, tolerance: float = 1e-4, xi=None, seed: int = 0,
                                             values=(1.0, 9.0), sigma_grid=None, x0=None, max_cycles: int = 1000,
-                                            group=None, log=None):
+                                            group=None, log=None, backend=None):
     """driver.checkerboard_homogenization over `world` ranks (one GPU each): the base mesh is split into blocks about
     the origin (halves / quadrants / octants for 2, 4, 8 ranks), so that the centred sub-domains the outer loop
     shrinks to stay balanced.  Every rank runs the same host loop; the per-cycle integrals are local sums
     added over the ranks, everything else goes through the partitioned V-cycle.  Returns (sigma, history) like the
     single-GPU driver, identical on every rank."""
-    import torch
-    import torch.distributed as dist
     dim = api._dim_of(eltype)
+    # the blocks are halves per axis about the origin: 1, 2, 4 (and 8 in 3D) ranks.  Checked on every rank before any
+    # collective, so that an unsupported size fails everywhere instead of hanging the ranks that do own cells
+    if world not in ((1, 2, 4) if dim == 2 else (1, 2, 4, 8)):
+        raise ValueError(f"partitioned_checkerboard_homogenization: {world} ranks are not supported in {dim}D "
+                         "(blocks are halves per axis: 1, 2, 4" + (", 8" if dim == 3 else "") + ")")
     xi = driver.random_unit_vec(dim) if xi is None else np.asarray(xi, dtype=np.float64)
     lam, sigma = 1.0, 0.0
     box_radius = driver.compute_box_radius(0, n)
@@ -234,7 +279,7 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
     owner = block_owner(base, blocks, width / 2.0, origin)          # halves per axis; axes with one block clamp to 0
     total_grids = refinements + 1
     grid = PartitionedGrid(ctx, base, total_grids, owner, rank, world)
-    Exchange(ctx, grid, group)
+    ex = Exchange(ctx, grid, group, backend)
     op = api.L2PlusDivAGrad(grid, lam, cond)
     states = [api.LevelState(grid, i + 1) for i in range(total_grids)]
     top = states[-1]
@@ -246,13 +291,7 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
     api.apply_constraint(top.x, total_grids, grid)
     api.rhs_axi_grad_v(top.b, grid, xi)
     v_prev = api.DeviceMatrix(grid, total_grids)
-    dev = torch.device("cuda", ctx.device)
-
-    def rank_sum(*vals):
-        t = torch.tensor(vals, dtype=torch.float64, device=dev)
-        dist.all_reduce(t, group=group)
-        return [float(v) for v in t.tolist()]
-
+    rank_sum = ex.rank_sum
     cur = base
     history = []
     for k in range(n + 1):

@@ -180,7 +180,28 @@ int hmg_grid_set_overlap(hmg_grid *grid, int enabled);
 /* level = 0: capacity needed for every level and for the coarse gather */
 int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *grid, int level);
 void *hmg_ctx_scalar_bank(hmg_ctx *ctx);
+/* device_doubles16 = NULL restores the library's own bank (call it before the caller-owned memory goes away) */
 int hmg_ctx_set_scalar_bank(hmg_ctx *ctx, void *device_doubles16);
+/* the context's HIP stream (a hipStream_t): a host layer that issues its own collectives must issue them here */
+void *hmg_ctx_stream(hmg_ctx *ctx);
+
+/* ---- in-library communicator: RCCL over xGMI, one rank per GPU ------------------------------------------------------
+ * The reference's exchange point is broadcast_interfaces! (src/implicit_fine_grid.jl:209-328; called at
+ * src/multigrid.jl:51,61,75) plus the three dot products of a CG step (src/multigrid.jl:54,64,67).  With a communicator
+ * the library does them itself: ncclAllReduce of the packed cut buffer (on a second HIP stream, event-ordered, when the
+ * overlap is on) and of the CG scalars (two neighbouring slots of the scalar bank at CG step 0: one call), all enqueued
+ * on streams -- no host code runs between two kernels of a V-cycle.  Usage: rank 0 calls hmg_comm_unique_id and hands
+ * the 128 bytes to every rank (any channel: MPI, a file, torch.distributed), every rank calls hmg_comm_init on its
+ * context, creates its grid with hmg_grid_create_partition and calls hmg_grid_use_comm.  librccl is opened at run time
+ * (dlopen), so single-GPU use does not need it. */
+#define HMG_COMM_ID_BYTES 128
+int hmg_comm_unique_id(void *out128);
+int hmg_comm_init(hmg_ctx *ctx, int nranks, int rank, const void *unique_id128);
+int hmg_comm_destroy(hmg_ctx *ctx);
+int hmg_comm_stats(hmg_ctx *ctx, int64_t *calls, int64_t *doubles);   /* collectives issued so far, doubles moved */
+int hmg_grid_use_comm(hmg_grid *grid);
+/* sum over ranks of `count` (<= 7) host doubles, in place, blocking: the driver's per-cycle integrals */
+int hmg_comm_sum_host(hmg_ctx *ctx, double *vals, int count);
 /* Grid of the cells owner[c] == rank of a global base mesh.  The library derives the local mesh, the cut
  * entities (global ids identical on all ranks), global multiplicities and Dirichlet / first-copy masks, and
  * keeps the global mesh for a replicated level-1 solve.  hmg_grid_set_operator takes the GLOBAL sigma.

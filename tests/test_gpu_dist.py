@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, levels, overlap, q):
+def _worker(rank, world, port, width, levels, overlap, q, own_stream=False):
     try:
         sys.path.insert(0, ROOT)
         import torch
@@ -34,7 +34,9 @@ def _worker(rank, world, port, width, levels, overlap, q):
         O.NTHREADS[0] = 2
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-        ctx = hmg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        # own_stream: a library-owned non-blocking stream that is NOT torch's current stream -- the callbacks must
+        # still order their collectives behind the pack kernels and before the unpack kernels
+        ctx = hmg.Context(0) if own_stream else hmg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
         if isinstance(width, str):   # "delaunay3" / "delaunay2": unstructured base mesh, ragged partition (hash of the cell id)
             dim = int(width[-1])
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -82,7 +84,7 @@ def _worker(rank, world, port, width, levels, overlap, q):
         r = sts[-1].r.copy(order="F")
         O.zero_out_all_but_one(r, gi, L)
         assert abs(hmg.norm_unique(dsts[-1].r) - np.linalg.norm(r)) <= 1e-8 * np.linalg.norm(r)
-        assert prob.exchange.calls > 0
+        assert prob.exchange.stats()[0] > 0
         dist.destroy_process_group()
         q.put((rank, "ok"))
     except Exception:                                                    # pragma: no cover
@@ -90,15 +92,17 @@ def _worker(rank, world, port, width, levels, overlap, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,width,levels,overlap", [(2, 4, 4, True), (2, 4, 4, False), (2, 2, 7, True), (4, 2, 4, True), (3, "delaunay3", 3, True),
-                                                        (2, "delaunay2", 5, True), (2, "delaunay2", 5, False)])
-def test_multi_rank_vcycle_matches_serial_oracle(world, width, levels, overlap):
+@pytest.mark.parametrize("world,width,levels,overlap,own_stream",
+                         [(2, 4, 4, True, False), (2, 4, 4, False, False), (2, 2, 7, True, False), (4, 2, 4, True, False),
+                          (3, "delaunay3", 3, True, False), (2, "delaunay2", 5, True, False), (2, "delaunay2", 5, False, False),
+                          (2, 4, 4, True, True), (2, 4, 4, False, True)])
+def test_multi_rank_vcycle_matches_serial_oracle(world, width, levels, overlap, own_stream):
     """overlap=True: cut-adjacent cells first, asynchronous sum over ranks in flight during the rest."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, width, levels, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, levels, overlap, q, own_stream)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
@@ -155,3 +159,53 @@ def test_partitioned_driver_matches_single_gpu_driver(world, n, dim, refinements
     for rank, msg in sorted(res):
         assert msg.startswith("ok"), f"rank {rank}: {msg}"
         assert int(msg.split()[1]) >= min_outer
+
+
+def test_in_library_rccl_communicator_single_rank(oracle):
+    """hmg_comm_init / hmg_grid_use_comm with a one-rank RCCL communicator (all a single-GPU box allows: RCCL refuses two
+    ranks on one device): the partitioned code path -- ncclAllReduce of the CG scalars and of the level-1 gather on the
+    context's stream, batched r.r + p.Ap -- gives the single-GPU result; then the partitioned driver through the same
+    communicator (hmg_comm_sum_host for the integrals)."""
+    import homogenization_jl_amd as hmg
+    from homogenization_jl_amd import driver, dist as hdist
+    O = oracle
+    ctx = hmg.Context(0)
+    try:
+        L, w = 4, 4
+        prob = hdist.partitioned_checkerboard(ctx, w, L, 1, 0, seed=3, backend="rccl")
+        g = prob.implicit
+        g1 = hmg.ImplicitFineGrid(ctx, prob.global_base, L)            # the same mesh and field, not partitioned
+        op1 = hmg.L2PlusDivAGrad(g1, 1.0, prob.cond)
+        np.testing.assert_array_equal(g.local_cells, np.arange(g1.ncells()))
+        sts_p = [hmg.LevelState(g, i + 1) for i in range(L)]
+        sts_s = [hmg.LevelState(g1, i + 1) for i in range(L)]
+        for st, gg in ((sts_p, g), (sts_s, g1)):
+            st[-1].x.rand(5); st[-1].b.rand(6)
+            hmg.broadcast_interfaces(st[-1].x, gg, L)
+            hmg.apply_constraint(st[-1].x, L, gg)
+        bl_p, bl_s = prob.base_level(), hmg.BaseLevel(g1)
+        for _ in range(2):
+            hmg.vcycle(g, bl_p, [prob.op] * L, sts_p, L, 3)
+            hmg.vcycle(g1, bl_s, [op1] * L, sts_s, L, 3)
+        a, b = sts_p[-1].x.to_host(), sts_s[-1].x.to_host()
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+        calls, doubles = prob.exchange.stats()
+        assert calls > 0 and doubles > 0
+        assert abs(hmg.norm_unique(sts_p[-1].r) - hmg.norm_unique(sts_s[-1].r)) <= 1e-12 * hmg.norm_unique(sts_s[-1].r)
+        assert prob.exchange.rank_sum(1.5, -2.0) == [1.5, -2.0]
+        sg = driver.generate_conductivity(3, 10, 31)
+        want, hist_s = driver.checkerboard_homogenization(0, hmg.Tet64, refinements=2, tolerance=1e-3, ctx=ctx, sigma_grid=sg, seed=4)
+        got, hist_p = hdist.partitioned_checkerboard_homogenization(ctx, 0, hmg.Tet64, 1, 0, refinements=2, tolerance=1e-3,
+                                                                    sigma_grid=sg, seed=4, backend="rccl")
+        assert len(hist_s) == len(hist_p) and abs(got - want) <= 1e-10 * max(1.0, abs(want))
+    finally:
+        ctx.close()
+
+
+def test_unsupported_world_size_raises_everywhere():
+    """3, 6, 16 ranks (or 8 in 2D) would leave ranks without cells: refused before any collective."""
+    import homogenization_jl_amd as hmg
+    from homogenization_jl_amd import dist as hdist
+    for world, tag in ((3, hmg.Tet64), (6, hmg.Tet64), (16, hmg.Tet64), (8, hmg.Tri64)):
+        with pytest.raises(ValueError):
+            hdist.partitioned_checkerboard_homogenization(None, 1, tag, world, 0)
