@@ -117,6 +117,17 @@ struct hmg_ctx {
     int64_t comm_calls = 0, comm_doubles = 0;
 };
 
+namespace {
+// state of the last coarse solve, copied to pinned host memory behind the solve and read when somebody asks
+struct CoarseProbe {
+    double *h = nullptr;            // pinned: S_DONE, S_ITER, S_CRR, b.b
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int budget = 0;                 // iterations launched by the solve the probe belongs to
+};
+
+}  // namespace
+
 struct hmg_grid {
     hmg_ctx *ctx = nullptr;
     int dim = 0, nlevels = 0;
@@ -142,6 +153,8 @@ struct hmg_grid {
     DevBuf<int32_t> c_rowptr, c_colidx, c_interior;
     DevBuf<double> c_val, c_diag, c_b, c_x, c_r, c_z, c_p, c_q, c_u;
     int coarse_last_it = 0;
+    int coarse_budget = 0;                       // iterations a solve enqueues blindly (0: not known yet)
+    std::unique_ptr<CoarseProbe> probe{new CoarseProbe};
     // multi-GPU
     std::unique_ptr<Partition> part;
     std::vector<double> sigma_global;
@@ -941,42 +954,92 @@ void coarse_setup(hmg_grid *g)
     g->cd.diag = g->c_diag.p;
     g->cd.interior = g->c_interior.p;
     g->coarse_ready = true;
+    g->coarse_budget = 0;                          // new matrix: the first solve counts its iterations again
 }
+
+void coarse_probe_wait(hmg_grid *g);
 
 void coarse_pcg(hmg_grid *g)
 {
     // Jacobi-PCG on (lambda M + K_sigma)[interior, interior] x = b to a relative residual of
     // coarse_rtol; stands in for the reference's CHOLMOD solve (src/multigrid.jl:84).
+    // Convergence is decided on the device: k_coarse_pupdate sets a flag once r.r <= rtol^2 b.b and every kernel of
+    // the later iterations returns at once, so a fixed number of iterations can be enqueued without a host round trip.
+    // The first solve after a (re)assembly finds that number the slow way (a look every coarse_check iterations);
+    // later solves enqueue 1.5 x the largest count seen + coarse_check, leave a probe (flag, count, r.r) behind in pinned
+    // memory and return; the probe is checked at the next solve (or when the iteration count is asked for).
     hmg_ctx *c = g->ctx;
     const Launch &L = c->L;
     const CoarseDev &A = g->cd;
-    g->coarse_last_it = 0;
-    if (A.n == 0) return;
+    if (A.n == 0) {
+        g->coarse_last_it = 0;
+        return;
+    }
+    coarse_probe_wait(g);                          // the previous solve's verdict (throws if it did not converge)
+    CoarseProbe &pr = *g->probe;
+    if (!pr.h) {
+        HIPCHK(hipHostMalloc((void **)&pr.h, 4 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&pr.ev, hipEventDisableTiming));
+    }
+    const double rtol2 = c->coarse_rtol * c->coarse_rtol;
     launch_coarse_init(L, A, g->c_b.p, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p);
-    double h[S_COUNT];
-    HIPCHK(hipMemcpyAsync(h, c->L.scal, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    const double bb = h[S_C2];
-    if (!(bb > 0.0)) return;   // b == 0 -> x == 0
-    const double tol2 = c->coarse_rtol * c->coarse_rtol * bb;
-    int it = 0;
     int slot_old = S_C0, slot_new = S_C3;          // r.z of the current / next iteration
-    while (it < c->coarse_maxit) {
-        int chunk = std::min(c->coarse_check, c->coarse_maxit - it);
-        for (int q = 0; q < chunk; ++q) {
+    auto iterate = [&](int count) {
+        for (int q = 0; q < count; ++q) {
             launch_coarse_spmv_dot(L, A, g->c_p.p, g->c_q.p);
             launch_coarse_update(L, A, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p, g->c_q.p, slot_old);
-            launch_coarse_pupdate(L, A, g->c_p.p, g->c_z.p, slot_old, slot_new);
+            launch_coarse_pupdate(L, A, g->c_p.p, g->c_z.p, slot_old, slot_new, rtol2);
             std::swap(slot_old, slot_new);
         }
-        launch_coarse_residual_norm(L, A);
-        it += chunk;
-        HIPCHK(hipMemcpyAsync(h, c->L.scal, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (!(h[S_TMP] > tol2)) break;
-        if (!std::isfinite(h[S_TMP])) throw std::runtime_error("coarse PCG diverged (non-finite residual)");
+    };
+    auto probe = [&]() {
+        HIPCHK(hipMemcpyAsync(pr.h, L.scal + S_DONE, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(pr.h + 3, L.scal + S_C2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(pr.ev, c->stream));
+        pr.pending = true;
+    };
+    if (g->coarse_budget > 0) {
+        iterate(g->coarse_budget);
+        pr.budget = g->coarse_budget;
+        probe();
+        return;
     }
-    g->coarse_last_it = it;
+    int it = 0;
+    while (it < c->coarse_maxit) {
+        const int chunk = std::min(c->coarse_check, c->coarse_maxit - it);
+        iterate(chunk);
+        it += chunk;
+        pr.budget = it;
+        probe();
+        HIPCHK(hipEventSynchronize(pr.ev));
+        pr.pending = false;
+        const double done = pr.h[0], rr = pr.h[2], bb = pr.h[3];
+        if (!std::isfinite(rr) || !std::isfinite(bb)) throw std::runtime_error("coarse PCG diverged (non-finite residual)");
+        if (done != 0.0 || !(bb > 0.0)) break;
+        if (it >= c->coarse_maxit)
+            throw std::runtime_error("coarse PCG: no convergence to coarse_rtol within coarse_maxit iterations");
+    }
+    g->coarse_last_it = (int)pr.h[1];
+    g->coarse_budget = std::min(c->coarse_maxit, (3 * std::max(g->coarse_last_it, 1)) / 2 + c->coarse_check);
+}
+
+// Blocks until the probe of the last budgeted solve has landed and judges it.
+void coarse_probe_wait(hmg_grid *g)
+{
+    if (!g->probe || !g->probe->pending) return;
+    CoarseProbe &pr = *g->probe;
+    HIPCHK(hipEventSynchronize(pr.ev));
+    pr.pending = false;
+    const double done = pr.h[0], rr = pr.h[2], bb = pr.h[3];
+    g->coarse_last_it = (int)pr.h[1];
+    if (!std::isfinite(rr) || !std::isfinite(bb)) throw std::runtime_error("coarse PCG diverged (non-finite residual)");
+    if (done == 0.0 && bb > 0.0) {
+        g->coarse_budget = 0;                      // next solve: find the count the slow way again
+        throw std::runtime_error("coarse PCG: the previous level-1 solve did not reach coarse_rtol within the " +
+                                 std::to_string(pr.budget) + " iterations enqueued for it");
+    }
+    g->coarse_budget = std::max(g->coarse_budget,
+                                std::min(g->ctx->coarse_maxit, (3 * std::max(g->coarse_last_it, 1)) / 2 + g->ctx->coarse_check));
 }
 
 void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
@@ -1450,6 +1513,8 @@ int hmg_grid_destroy(hmg_grid *grid)
     HMG_TRY
     if (grid) {
         if (grid->ctx) (void)hipStreamSynchronize(grid->ctx->stream);
+        if (grid->probe && grid->probe->h) (void)hipHostFree(grid->probe->h);
+        if (grid->probe && grid->probe->ev) (void)hipEventDestroy(grid->probe->ev);
         delete grid;
     }
     HMG_END
@@ -2057,7 +2122,17 @@ int hmg_coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
     HMG_END
 }
 
-int hmg_coarse_last_iterations(const hmg_grid *g) { return g ? g->coarse_last_it : -1; }
+int hmg_coarse_last_iterations(const hmg_grid *g)
+{
+    if (!g) return -1;
+    try {
+        coarse_probe_wait(const_cast<hmg_grid *>(g));
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return -1;
+    }
+    return g->coarse_last_it;
+}
 
 int hmg_vcycle(hmg_grid *g, int top_level, int steps, int steps_coarse, hmg_vec **states)
 {
@@ -2212,8 +2287,8 @@ int hmg_comm_sum_host(hmg_ctx *ctx, double *vals, int count)
     HMG_TRY
     need(ctx && vals, "null argument");
     need(ctx->comm != nullptr, "hmg_comm_init must be called first");
-    need(count >= 1 && count <= 7, "count must be 1..7");
-    double *d = ctx->L.scal + 9;     // (slots 9..15 of the scalar bank are not used by the kernels)
+    need(count >= 1 && count <= S_COUNT - S_HOST, "count must be 1..4");
+    double *d = ctx->L.scal + S_HOST;     // (the last slots of the scalar bank are not used by the kernels)
     HIPCHK(hipMemcpyAsync(d, vals, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
     comm_allreduce(ctx, d, count, ctx->stream);
     HIPCHK(hipMemcpyAsync(vals, d, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));

@@ -106,7 +106,10 @@ struct CoarseDev {
 };
 
 // scalar bank slots (device doubles)
-enum { S_RS = 0, S_PAP = 1, S_RS2 = 2, S_TMP = 3, S_C0 = 4, S_C1 = 5, S_C2 = 6, S_C3 = 7, S_PAP2 = 8, S_COUNT = 16 };
+// (S_DONE / S_ITER / S_CRR: device-side state of the coarse PCG -- converged flag, iterations done, last r.r;
+//  slots 12..15: host sums of hmg_comm_sum_host)
+enum { S_RS = 0, S_PAP = 1, S_RS2 = 2, S_TMP = 3, S_C0 = 4, S_C1 = 5, S_C2 = 6, S_C3 = 7, S_PAP2 = 8, S_DONE = 9, S_ITER = 10,
+       S_CRR = 11, S_HOST = 12, S_COUNT = 16 };
 
 struct Launch {
     hipStream_t stream;
@@ -187,14 +190,16 @@ void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, dou
 void launch_coarse_gather_rhs(const Launch &L, const CoarseDev &A, const double *u, double *b);
 void launch_coarse_scatter_sol(const Launch &L, const CoarseDev &A, int64_t nnodes, const double *x, double *u);
 void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z,
-                        double *p);   // x=0,r=b,z=r/d,p=z, scal[S_C0]=r.z, scal[S_C2]=b.b
+                        double *p);   // x=0,r=b,z=r/d,p=z, scal[S_C0]=r.z, scal[S_C2]=b.b, S_DONE = S_ITER = 0
 // one iteration = these three launches; r.z lives in scal[slot_old] -> scal[slot_new] (S_C0 / S_C3, exchanged by the
 // caller every iteration), the other dot products stay in block partials that the consumer kernel sums itself
 void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q);   // partials of p.q
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
                           const double *q, int slot_old);   // alpha = rz/p.q; partials of r.z (new), r.r
 void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z, int slot_old,
-                           int slot_new);                   // beta = rz_new/rz_old; scal[slot_new] = rz_new
+                           int slot_new, double rtol2);     // beta = rz_new/rz_old; scal[slot_new] = rz_new; sets
+                                                            // S_DONE once r.r <= rtol2 * b.b: all three kernels of the
+                                                            // later iterations then return at once
 void launch_coarse_residual_norm(const Launch &L, const CoarseDev &A);   // scal[S_TMP] = r.r of the last update
 
 // b[slot, cell] = dot(dphi[slot], pvec[cell])   (rhs_a xi grad v)

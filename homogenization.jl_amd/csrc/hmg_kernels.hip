@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 #define HMG_STAMP(i)
 #endif
 
-template <int DIM, int NT, int SPT, bool FUSED, int RB>
+template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false>   // WD: instantiation for the driver integrals (flags bit 3)
 __global__ void __launch_bounds__(NT, NT >= 640 ? 8 : 1)   // 2 x 1024 / 3 x 640 threads per CU need <= 64 VGPRs
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
@@ -234,7 +234,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
 #pragma unroll
         for (int q = 0; q < 4; ++q) mq[q] = a.mult ? __builtin_amdgcn_readfirstlane(mp[q]) : 0x01010101u;   // (no table: all 1)
     }
-    const bool wdot = FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
+    const bool wdot = WD && FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
     HMG_STAMP(2);   // tables requested, before the barrier
     __syncthreads();
     HMG_STAMP(3);
@@ -355,7 +355,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
 // phases are single batched / software-pipelined loops instead of one latency-bound loop per entity.  The window
 // is sized so that two workgroups are resident per CU (one loads while the other computes).  Same arithmetic as
 // k_apply.
-template <int DIM, int NT, bool FUSED>
+template <int DIM, int NT, bool FUSED, bool WD = false>
 __global__ void __launch_bounds__(NT, 8)
 k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a, SlabTables st)
 {
@@ -399,7 +399,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
 #pragma unroll
         for (int q = 0; q < 4; ++q) mq[q] = a.mult ? __builtin_amdgcn_readfirstlane(mp[q]) : 0x01010101u;
     }
-    const bool wdot = FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
+    const bool wdot = WD && FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
     double rr = 0.0, pap = 0.0;
     auto plane_off = [&](int k) {   // PO(k) = number of lattice nodes in planes < k
         if (k <= 0) return 0;
@@ -576,10 +576,10 @@ size_t apply_lds_bytes(const LevelDev &lv)
     return sizeof(double) * (size_t)(WSZ + lv.lds_g0 + lv.nf + lv.lds_g1);
 }
 
-template <int DIM, int NT, int SPT, bool FUSED, int RB = 0>
+template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
-    auto kern = k_apply<DIM, NT, SPT, FUSED, RB>;
+    auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD>;
     if (FUSED && a.xcoarse) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -589,13 +589,13 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
     check_launch();
 }
 
-template <int DIM, bool FUSED>
+template <int DIM, bool FUSED, bool WD = false>
 static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a)
 {
     const size_t lds = apply_lds_bytes(lv);
     if (lds > 160 * 1024) {
         if (DIM != 3 || !mesh.slab.head) throw std::runtime_error("operator apply: cell does not fit the LDS");
-        auto kern = k_apply_slab<3, 1024, FUSED>;
+        auto kern = k_apply_slab<3, 1024, FUSED, WD>;
         const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab.lds_nodes);
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
@@ -610,25 +610,28 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         launch_apply_pipe(L, lv, mesh, a, FUSED);
         return;
     }
-    int nt = L.apply_threads;
+    int nt = WD ? 0 : L.apply_threads;   // (the integral instantiations exist for the automatic workgroup sizes only)
     // (small cells are bound by the number of waves launched, not by their work: as few waves per cell as hold it)
     if (nt == 0) nt = nf <= 64 ? 64 : nf <= 192 ? 192 : nf <= 2048 ? 256 : 1024;
     if (nt <= 64)
-        launch_apply_generic<DIM, 64, 1, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 64, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 192 && nf <= 192)
-        launch_apply_generic<DIM, 192, 1, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 192, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 256 && nf <= 1024)
-        launch_apply_generic<DIM, 256, 4, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 256, 4, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 256)
-        launch_apply_generic<DIM, 256, 8, FUSED>(L, lv, mesh, a, lds);
-    else if (nt <= 512)
-        launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
-    else if (nt <= 640)
-        launch_apply_generic<DIM, 640, 11, FUSED>(L, lv, mesh, a, lds);
-    else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked)
-        launch_apply_generic<DIM, 1024, 7, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 256, 8, FUSED, 0, WD>(L, lv, mesh, a, lds);
+    else if (nt <= 640) {
+        if constexpr (!WD) {
+            if (nt <= 512)
+                launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
+            else
+                launch_apply_generic<DIM, 640, 11, FUSED>(L, lv, mesh, a, lds);
+        }
+    } else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked)
+        launch_apply_generic<DIM, 1024, 7, FUSED, DIM == 3 ? 6 : 0, WD>(L, lv, mesh, a, lds);
     else
-        launch_apply_generic<DIM, 1024, 7, FUSED>(L, lv, mesh, a, lds);
+        launch_apply_generic<DIM, 1024, 7, FUSED, 0, WD>(L, lv, mesh, a, lds);
 }
 
 void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
@@ -664,6 +667,13 @@ void launch_apply_fused_kernel(const Launch &L, const LevelDev &lv, const MeshDe
     a.scal = L.scal;
     if (!(a.flags & 32)) a.mult = mesh.mult;     // (bit 5: caller wants unit multiplicities -- a.mult stays null)
     a.blockpart = mesh.blockpart;
+    if (a.flags & 8) {                            // the driver integrals: src multiplies (own instantiations)
+        if (lv.dim == 3)
+            launch_apply_dim<3, true, true>(L, lv, mesh, a);
+        else
+            launch_apply_dim<2, true, true>(L, lv, mesh, a);
+        return;
+    }
     if (lv.dim == 3)
         launch_apply_dim<3, true>(L, lv, mesh, a);
     else
@@ -1453,9 +1463,10 @@ k_coarse_init(CoarseDev A, const double *__restrict__ b, double *x, double *r, d
 }
 
 __global__ void __launch_bounds__(256)
-k_coarse_spmv_dot(CoarseDev A, const double *__restrict__ p, double *q, double *partials)
+k_coarse_spmv_dot(CoarseDev A, const double *__restrict__ p, double *q, double *partials, const double *__restrict__ scal)
 {
     __shared__ double red[4];
+    if (scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0)) return;   // converged (or b == 0: x stays 0): a no-op from here on
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
         double s = 0.0;
@@ -1478,6 +1489,7 @@ k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__re
 {
     __shared__ double red[4];
     __shared__ double bc;
+    if (scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0)) return;
     const double pap = sum_partials_all(part_pap, nb, red, &bc);
     // exact convergence (r = 0, e.g. a 1-unknown system after one step) makes p.Ap = 0: stay at the solution
     const double alpha = pap != 0.0 ? scal[slot_old] / pap : 0.0;
@@ -1502,16 +1514,28 @@ k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__re
 // beta = rz_new / rz_old; p = z + beta p; block 0 publishes rz_new in scal[slot_new]
 __global__ void __launch_bounds__(256)
 k_coarse_pupdate(CoarseDev A, double *p, const double *__restrict__ z, double *scal, int slot_old, int slot_new,
-                 const double *__restrict__ part_rz, int nb)
+                 const double *__restrict__ part_rz, const double *__restrict__ part_rr, int nb, double rtol2)
 {
     __shared__ double red[4];
     __shared__ double bc;
+    // (block 0 sets the flag at the end of THIS launch, possibly while another block starts: one thread reads it for
+    //  its block, so the early return is block-uniform; a block that still sees 0 does one more harmless p-update)
+    __shared__ int skip;
+    if (threadIdx.x == 0) skip = scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0);
+    __syncthreads();
+    if (skip) return;
     const double rz_new = sum_partials_all(part_rz, nb, red, &bc);
+    const double rr = sum_partials_all(part_rr, nb, red, &bc);
     const double rz_old = scal[slot_old];
     const double beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = z[i] + beta * p[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot_new] = rz_new;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal[slot_new] = rz_new;
+        scal[S_ITER] += 1.0;
+        scal[S_CRR] = rr;
+        if (rr <= rtol2 * scal[S_C2]) scal[S_DONE] = 1.0;     // (NaN compares false: the budget runs out, the host sees S_CRR)
+    }
 }
 
 static inline int coarse_blocks(const Launch &L, int64_t n)
@@ -1542,13 +1566,14 @@ void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, do
     check_launch();
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, nb, L.scal, (int)S_C0);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, nb, L.scal, (int)S_C2);
+    HMG_HIP_CHECK(hipMemsetAsync(L.scal + S_DONE, 0, 3 * sizeof(double), L.stream));   // S_DONE, S_ITER, S_CRR
     check_launch();
 }
 // partial buffers of the PCG inside L.partials (>= 4096 doubles, nb <= 1024): P0 p.Ap, P1 r.z, P2 r.r
 void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q)
 {
     int nb = coarse_blocks(L, A.n);
-    hipLaunchKernelGGL(k_coarse_spmv_dot, dim3(nb), dim3(256), 0, L.stream, A, p, q, L.partials);
+    hipLaunchKernelGGL(k_coarse_spmv_dot, dim3(nb), dim3(256), 0, L.stream, A, p, q, L.partials, L.scal);
     check_launch();
 }
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
@@ -1559,11 +1584,12 @@ void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double
                        L.partials + 1024, L.partials + 2048);
     check_launch();
 }
-void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z, int slot_old, int slot_new)
+void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z, int slot_old, int slot_new,
+                           double rtol2)
 {
     int nb = coarse_blocks(L, A.n);
     hipLaunchKernelGGL(k_coarse_pupdate, dim3(nb), dim3(256), 0, L.stream, A, p, z, L.scal, slot_old, slot_new,
-                       L.partials + 1024, nb);
+                       L.partials + 1024, L.partials + 2048, nb, rtol2);
     check_launch();
 }
 // r.r of the last update -> scal[S_TMP] (convergence check)

@@ -200,7 +200,7 @@ int hmg_comm_init(hmg_ctx *ctx, int nranks, int rank, const void *unique_id128);
 int hmg_comm_destroy(hmg_ctx *ctx);
 int hmg_comm_stats(hmg_ctx *ctx, int64_t *calls, int64_t *doubles);   /* collectives issued so far, doubles moved */
 int hmg_grid_use_comm(hmg_grid *grid);
-/* sum over ranks of `count` (<= 7) host doubles, in place, blocking: the driver's per-cycle integrals */
+/* sum over ranks of `count` (<= 4) host doubles, in place, blocking: the driver's per-cycle integrals */
 int hmg_comm_sum_host(hmg_ctx *ctx, double *vals, int count);
 /* Grid of the cells owner[c] == rank of a global base mesh.  The library derives the local mesh, the cut
  * entities (global ids identical on all ranks), global multiplicities and Dirichlet / first-copy masks, and
