@@ -57,6 +57,48 @@ def cpu_baseline(sample_width, levels, steps_top):
                       f"({m.nelements()} of the workload's cells), L={levels}, {dt:.2f} s"}
 
 
+def time_to_tolerance(ctx, hmg, driver, n, refinements, tolerance):
+    """Wall-clock of the whole driver, `checkerboard_homogenization(n, Tet64, refinements, tolerance)`, on this GPU:
+    host setup and the outer loop (V-cycles, integrals, domain shrinks) split out."""
+    tm = {}
+    t0 = time.perf_counter()
+    sigma, hist = driver.checkerboard_homogenization(n, hmg.Tet64, refinements=refinements, tolerance=tolerance, ctx=ctx,
+                                                     seed=0, timings=tm)
+    return {"call": f"checkerboard_homogenization({n}, Tet64, refinements={refinements}, tolerance={tolerance:g})",
+            "seconds": time.perf_counter() - t0, "setup_seconds": tm["setup_s"], "solve_seconds": tm["solve_s"],
+            "vcycles": tm["vcycles"], "outer_steps": tm["outer_steps"], "sigma": sigma,
+            "base_mesh": f"{tm['width']}^3 unit cubes, {tm['cells']} cells"}
+
+
+def cpu_time_to_tolerance(hmg, driver, n, refinements, tolerance, max_seconds):
+    """The same driver through the oracle (CPU restatement) on this host's cores, same coefficient field and initial
+    guess; stopped after max_seconds (then the V-cycle count reached is reported and `seconds` is a lower bound)."""
+    from oracle import oracle as O
+    width = 2 * (driver.compute_box_radius(0, n) + driver.compute_boundary_layer(1.0, n))
+    sgrid = driver.generate_conductivity(3, width, 0)
+    nf = (2 ** refinements + 1) * (2 ** refinements + 2) * (2 ** refinements + 3) // 6
+    x0 = hmg.host_random((nf, 6 * width ** 3), 1)
+    t0 = time.perf_counter()
+    done = {"cycles": 0}
+
+    class Stop(Exception):
+        pass
+
+    def log(h):
+        done["cycles"] += 1
+        if time.perf_counter() - t0 > max_seconds:
+            raise Stop()
+    sigma, complete = None, True
+    try:
+        sigma, hist = O.checkerboard_homogenization(n=n, dim=3, refinements=refinements, tolerance=tolerance,
+                                                    sigma_grid=sgrid, x0=x0, log=log)
+    except Stop:
+        complete = False
+    return {"call": f"checkerboard_homogenization({n}, Tet64, refinements={refinements}, tolerance={tolerance:g})",
+            "seconds": time.perf_counter() - t0, "vcycles": done["cycles"], "complete": complete, "sigma": sigma,
+            "cores": int(O.available_cores()), "kind": "port"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +110,9 @@ def main():
     ap.add_argument("--sigma-high", type=float, default=9.0, help="checkerboard contrast: sigma in {1, SIGMA_HIGH}")
     ap.add_argument("--cpu-sample-width", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-time-to-tolerance", action="store_true", help="skip the whole-driver wall-clock runs")
+    ap.add_argument("--cpu-driver-seconds", type=float, default=75.0,
+                    help="time limit of the CPU oracle's run of the driver on BASELINE config 2")
     ap.add_argument("--apply-threads", type=int, default=None)
     args = ap.parse_args()
 
@@ -204,6 +249,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_width, L, args.smoothing_steps)
+        if world == 1 and not args.no_time_to_tolerance and (w, L) == (32, 6):
+            # outside the timed region: wall-clock to tolerance = 1e-5 of the whole driver (north_star).  n = 2,
+            # refinements = 5 IS BASELINE config 3 (width 2 (2^2 + 4 * 3) = 32); n = 1, refinements = 4 is config 2,
+            # the largest the CPU oracle finishes in about a minute.  The bench's own level vectors go back first.
+            for st in states:
+                st.close()
+            ttt = {"config3": time_to_tolerance(ctx, hmg, driver, 2, 5, 1e-5),
+                   "config2": time_to_tolerance(ctx, hmg, driver, 1, 4, 1e-5)}
+            if not args.no_cpu_baseline:
+                ttt["config2_cpu"] = cpu_time_to_tolerance(hmg, driver, 1, 4, 1e-5, args.cpu_driver_seconds)
+            out["time_to_tolerance"] = ttt
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -144,7 +144,8 @@ def checkerboard_problem(ctx, eltype, width: int, levels: int, seed: int = 0, va
 
 def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, smoothing_steps: int = 3,
                                 tolerance: float = 1e-4, xi=None, save=None, *, ctx=None, seed: int = 0,
-                                values=(1.0, 9.0), sigma_grid=None, x0=None, max_cycles: int = 1000, log=None):
+                                values=(1.0, 9.0), sigma_grid=None, x0=None, max_cycles: int = 1000, log=None,
+                                timings: dict | None = None):
     """checkerboard_homogenization(n, type; refinements, smoothing_steps, tolerance, xi, save) -> sigma
     (src/examples/homogenized_coefficients.jl:174-343) with every level-vector operation on the device.
 
@@ -153,7 +154,11 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     reference: checkerboard.vtu + one ahom_k.vtu per outer step, see vtk.py) may also be a (level, directory) pair;
     the level-1 solve is the library's PCG; a domain shrink keeps the level vectors in place
     (their columns are a prefix) instead of copying slices.  Returns (sigma, history) where history holds
-    (k, cycle, norm(r), sigma + dsigma, |dsigma - dsigma_prev|) -- the three quantities the reference logs."""
+    (k, cycle, norm(r), sigma + dsigma, |dsigma - dsigma_prev|) -- the three quantities the reference logs.
+    `timings` (a dict) receives wall-clock seconds: "setup_s" (mesh, tables, level vectors, x0, right-hand side -- up to
+    the first V-cycle), "solve_s" (everything after), "vcycles", "outer_steps", "cells"."""
+    import time
+    t_start = time.perf_counter()
     save_dir = "."
     if isinstance(save, tuple):
         save, save_dir = save
@@ -191,6 +196,8 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     v_prev = api.DeviceMatrix(implicit, total_grids)
     cur = base
     history = []
+    ctx.sync()
+    t_setup = time.perf_counter()
     for k in range(n + 1):
         base_level = api.BaseLevel(implicit)             # level-1 operator for the current lam / domain
         dsig, dsig_prev = 0.0, 0.0
@@ -227,8 +234,17 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
         v_prev.copyto(top.x)
         op.lam = lam
         api.next_rhs(top.b, top.x, implicit)
+    ctx.sync()
+    if timings is not None:
+        timings.update(setup_s=t_setup - t_start, solve_s=time.perf_counter() - t_setup, vcycles=len(history),
+                       outer_steps=len({h[0] for h in history}), cells=int(base.elements.shape[0]), width=int(width))
+    # the level vectors go back now, not whenever the collector gets to them (71 GB at BASELINE config 3)
+    for st in states:
+        st.close()
+    v_prev.close()
+    implicit.close()
     if own_ctx:
-        ctx.sync()
+        ctx.close()
     return sigma, history
 
 
