@@ -152,6 +152,7 @@ def main():
 
     L = args.levels
     w = args.width
+    t_setup0 = time.perf_counter()
     if world > 1 or force_part:
         from homogenization_jl_amd import dist as hdist
         prob = hdist.partitioned_checkerboard(ctx, w, L, world, rank, seed=0, values=(1.0, args.sigma_high))
@@ -173,6 +174,8 @@ def main():
     hmg.rhs_axi_grad_v(top.b, implicit, driver.random_unit_vec(3))
     base_level = prob.base_level() if (world > 1 or force_part) else hmg.BaseLevel(implicit)
     ops = [op] * L
+    ctx.sync()
+    setup_seconds = time.perf_counter() - t_setup0     # mesh synthesis, tables, partition, level vectors, x0, b, level-1 matrix
 
     def barrier():
         if dist is not None:
@@ -191,7 +194,8 @@ def main():
     dt = time.perf_counter() - t0
     if (world > 1 or force_part) and os.environ.get("HMG_EXCHANGE_STATS") == "1":
         ex = prob.exchange
-        print(f"[rank {rank}] exchange: {ex.calls} collectives, {ex.doubles * 8 / 1e6:.1f} MB, "
+        ncalls, ndoubles = ex.stats()
+        print(f"[rank {rank}] exchange ({ex.backend}): {ncalls} collectives, {ndoubles * 8 / 1e6:.1f} MB, "
               f"{ex.seconds:.3f} s host time inside them (warm-up included)", file=sys.stderr, flush=True)
     launches, ms, nbytes = ctx.apply_timing()
     ctx.set_option("time_apply", 0)
@@ -239,6 +243,7 @@ def main():
                        "smoothing_steps": args.smoothing_steps, "smoothing_steps_coarse": 2,
                        "coarse_solver": "device Jacobi-PCG rtol 1e-13",
                        "coarse_iterations_last": base_level.last_iterations(),
+                       "setup_seconds": setup_seconds,
                        "residual_norm_after": rnorm},
             "roofline": {"bound": "hbm",
                          "kernel": "hmg::k_apply<3,1024,7,*> (finest-level operator apply per V-cycle: 1 residual, 6 fused CG passes, 2 residuals with the pending x-updates / the prolongation folded in)",

@@ -89,6 +89,10 @@ SIGNATURES = {
     "hmg_comm_stats": (c_int, [vp, p_i64, p_i64]),
     "hmg_comm_sum_host": (c_int, [vp, p_f64, c_int]),
     "hmg_grid_use_comm": (c_int, [vp]),
+    "hmg_checkerboard_mesh_size": (c_int, [c_int, p_i64, p_i64, p_i64]),
+    "hmg_checkerboard_mesh": (c_int, [c_int, p_i64, p_f64, c_int, c_int, p_f64, p_i64]),
+    "hmg_block_owner": (c_int, [c_int, c_i64, p_f64, c_i64, p_i64, p_i64, c_f64, p_f64, p_i32]),
+    "hmg_conductivity_per_element": (c_int, [c_int, c_i64, p_f64, c_i64, p_i64, p_i64, p_f64, p_f64, p_f64]),
     "hmg_grid_create_partition": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, p_i32, c_int, c_int, pp]),
 }
 

@@ -7,11 +7,59 @@
 // identically ordered run in both columns, and (2) a 15-point (3D) / 7-point (2D) lattice stencil
 // in "class" form (one coefficient row per entity of the reference simplex).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace hmg {
+
+// Host threads for the setup work (table builders, mesh synthesis): HMG_SETUP_THREADS, else the hardware's, at most 16.
+int setup_threads();
+
+// f(begin, end) over [0, n) in contiguous pieces, one per thread.
+template <class F>
+void parallel_for(int64_t n, F f)
+{
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / 4096));
+    if (T == 1) {
+        f((int64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&, t] { f(n * t / T, n * (t + 1) / T); });
+    for (auto &x : th) x.join();
+}
+
+// Sort with a strict weak order: the pieces are sorted by one thread each, then merged pairwise (in parallel per
+// round).  Equal elements keep no particular order -- callers use total orders.
+template <class T, class Cmp>
+void parallel_sort(std::vector<T> &v, Cmp cmp)
+{
+    const int64_t n = (int64_t)v.size();
+    int P = 1;
+    while (P * 2 <= setup_threads() && n / (P * 2) >= 32768) P *= 2;
+    if (P == 1) {
+        std::sort(v.begin(), v.end(), cmp);
+        return;
+    }
+    std::vector<int64_t> cut(P + 1);
+    for (int p = 0; p <= P; ++p) cut[p] = n * p / P;
+    {
+        std::vector<std::thread> th;
+        for (int p = 0; p < P; ++p) th.emplace_back([&, p] { std::sort(v.begin() + cut[p], v.begin() + cut[p + 1], cmp); });
+        for (auto &x : th) x.join();
+    }
+    for (int w = 1; w < P; w *= 2) {
+        std::vector<std::thread> th;
+        for (int p = 0; p + w < P; p += 2 * w)
+            th.emplace_back([&, p, w] {
+                std::inplace_merge(v.begin() + cut[p], v.begin() + cut[p + w], v.begin() + cut[std::min(p + 2 * w, P)], cmp);
+            });
+        for (auto &x : th) x.join();
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Per-level tables of the refined reference simplex.
@@ -96,6 +144,8 @@ struct MeshTables {
     std::vector<int32_t> node_ptr, node_ent;
     // every base node: first listed copy (cell*8 + local node), for the level-1 gather
     std::vector<int32_t> node_first;
+    // every base node: all its copies (cell*8 + local node, ascending cell), CSR -- row-wise assembly of the level-1 matrix
+    std::vector<int32_t> node_all_ptr, node_all_ent;
     // per cell: Dirichlet entity bitmask and "not the first copy" bitmask; bit = cls-1
     std::vector<uint16_t> dmask, dupmask;
     // per cell, 16 bytes: number of copies of each of the cell's entities (same bit order as the masks)

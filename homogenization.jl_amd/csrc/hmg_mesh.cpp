@@ -10,10 +10,22 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 #include <unordered_set>
 
 namespace hmg {
+
+int setup_threads()
+{
+    static const int T = [] {
+        int t = 0;
+        if (const char *e = std::getenv("HMG_SETUP_THREADS")) t = std::atoi(e);
+        if (t <= 0) t = (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(t, 16));
+    }();
+    return T;
+}
 
 namespace {
 
@@ -37,25 +49,27 @@ std::vector<Ent> list_entities(const MeshTables &M, int kind /*0 node,1 edge,2 f
 {
     const int N = M.dim + 1;
     const int per = kind == 0 ? N : kind == 1 ? (M.dim == 3 ? 6 : 3) : 4;
-    std::vector<Ent> v;
-    v.reserve((size_t)M.ncells * per);
-    for (int64_t c = 0; c < M.ncells; ++c) {
-        const int32_t *el = &M.cells[c * N];
-        for (int l = 0; l < per; ++l) {
-            Ent e;
-            e.cell = (int32_t)c;
-            e.lid = l;
-            if (kind == 0)
-                e.key = {el[l], -1, -1};
-            else if (kind == 1) {
-                const int *t = M.dim == 3 ? TET_EDGES[l] : TRI_EDGES[l];
-                e.key = {el[t[0]], el[t[1]], -1};
-            } else
-                e.key = {el[TET_FACES[l][0]], el[TET_FACES[l][1]], el[TET_FACES[l][2]]};
-            v.push_back(e);
+    std::vector<Ent> v((size_t)M.ncells * per);
+    parallel_for(M.ncells, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) {
+            const int32_t *el = &M.cells[c * N];
+            for (int l = 0; l < per; ++l) {
+                Ent e;
+                e.cell = (int32_t)c;
+                e.lid = l;
+                if (kind == 0)
+                    e.key = {el[l], -1, -1};
+                else if (kind == 1) {
+                    const int *t = M.dim == 3 ? TET_EDGES[l] : TRI_EDGES[l];
+                    e.key = {el[t[0]], el[t[1]], -1};
+                } else
+                    e.key = {el[TET_FACES[l][0]], el[TET_FACES[l][1]], el[TET_FACES[l][2]]};
+                v[(size_t)c * per + l] = e;
+            }
         }
-    }
-    std::sort(v.begin(), v.end(), ent_less);
+    });
+    // ((key, cell) is a total order up to the local id, and one cell lists an entity once)
+    parallel_sort(v, ent_less);
     return v;
 }
 
@@ -115,7 +129,11 @@ Geo cell_geo(const MeshTables &M, int64_t c)
     return g;
 }
 
-void build_from_cells0(MeshTables &M)
+struct EntLists {
+    std::vector<Ent> faces, edges, nodes;   // sorted by (key, cell)
+};
+
+void build_from_cells0(MeshTables &M, EntLists *keep = nullptr)
 {
     const int dim = M.dim, N = dim + 1;
     const int nface = dim == 3 ? 4 : 0, nedge = dim == 3 ? 6 : 3;
@@ -165,6 +183,7 @@ void build_from_cells0(MeshTables &M)
             } else
                 throw std::runtime_error("base mesh: a face is shared by more than two cells");
         });
+        if (keep) keep->faces.swap(faces);
     }
     {
         auto edges = list_entities(M, 1);
@@ -189,9 +208,17 @@ void build_from_cells0(MeshTables &M)
                 M.edge_ptr.push_back((int32_t)M.edge_ent.size());
             }
         });
+        if (keep) keep->edges.swap(edges);
     }
     {
         auto nodes = list_entities(M, 0);
+        M.node_all_ptr.assign(M.nnodes + 1, 0);
+        M.node_all_ent.resize(nodes.size());
+        for (size_t q = 0; q < nodes.size(); ++q) {
+            M.node_all_ptr[nodes[q].key[0] + 1] += 1;
+            M.node_all_ent[q] = nodes[q].cell * 8 + nodes[q].lid;
+        }
+        for (int64_t g = 0; g < M.nnodes; ++g) M.node_all_ptr[g + 1] += M.node_all_ptr[g];
         for_groups(nodes, [&](size_t i, size_t j) {
             int32_t g = nodes[i].key[0];
             M.node_first[g] = nodes[i].cell * 8 + nodes[i].lid;
@@ -206,23 +233,37 @@ void build_from_cells0(MeshTables &M)
                 M.node_ptr.push_back((int32_t)M.node_ent.size());
             }
         });
+        if (keep) keep->nodes.swap(nodes);
     }
 
     M.detj.resize(M.ncells);
     M.jinv.resize((size_t)M.ncells * dim * dim);
-    for (int64_t c = 0; c < M.ncells; ++c) {
-        Geo g = cell_geo(M, c);
-        if (!(g.det > 0.0)) throw std::runtime_error("base mesh: degenerate cell");
-        M.detj[c] = g.det;
-        for (int b = 0; b < dim; ++b)
-            for (int a = 0; a < dim; ++a) M.jinv[(size_t)c * dim * dim + a + dim * b] = g.Jinv[a][b];
-    }
+    std::vector<char> bad(1, 0);
+    parallel_for(M.ncells, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) {
+            Geo g = cell_geo(M, c);
+            if (!(g.det > 0.0)) bad[0] = 1;
+            M.detj[c] = g.det;
+            for (int b = 0; b < dim; ++b)
+                for (int a = 0; a < dim; ++a) M.jinv[(size_t)c * dim * dim + a + dim * b] = g.Jinv[a][b];
+        }
+    });
+    if (bad[0]) throw std::runtime_error("base mesh: degenerate cell");
 }
 
 }  // namespace
 
+static void build_mesh_tables_keep(int dim, int64_t nnodes, const double *coords, int64_t ncells,
+                                   const int64_t *cells_1based, MeshTables &M, EntLists *keep);
+
 void build_mesh_tables(int dim, int64_t nnodes, const double *coords, int64_t ncells,
                        const int64_t *cells_1based, MeshTables &M)
+{
+    build_mesh_tables_keep(dim, nnodes, coords, ncells, cells_1based, M, nullptr);
+}
+
+static void build_mesh_tables_keep(int dim, int64_t nnodes, const double *coords, int64_t ncells,
+                                   const int64_t *cells_1based, MeshTables &M, EntLists *keep)
 {
     if (dim != 2 && dim != 3) throw std::runtime_error("dim must be 2 or 3");
     if (ncells <= 0 || nnodes <= 0) throw std::runtime_error("empty base mesh");
@@ -238,7 +279,7 @@ void build_mesh_tables(int dim, int64_t nnodes, const double *coords, int64_t nc
         if (v < 0 || v >= nnodes) throw std::runtime_error("base mesh: node index out of range (cells are 1-based)");
         M.cells[q] = (int32_t)v;
     }
-    build_from_cells0(M);
+    build_from_cells0(M, keep);
 }
 
 void restrict_mesh_tables(const MeshTables &full, int64_t ncells_prefix, int64_t nnodes_prefix,
@@ -263,7 +304,8 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
     part.rank = rank;
     part.nranks = nranks;
     MeshTables &G = part.global;
-    build_mesh_tables(dim, nnodes, coords, ncells, cells_1based, G);
+    EntLists glists;                         // the global entity lists, sorted once, reused for the cut analysis below
+    build_mesh_tables_keep(dim, nnodes, coords, ncells, cells_1based, G, &glists);
     const int N = dim + 1;
     const int nface = dim == 3 ? 4 : 0, nedge = dim == 3 ? 6 : 3;
 
@@ -331,7 +373,7 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
         part.gid[kind].clear();
         part.cell_lid[kind].clear();
         if (kind == 0 && dim != 3) continue;
-        auto ents = list_entities(G, kind == 0 ? 2 : kind == 1 ? 1 : 0);
+        const std::vector<Ent> &ents = kind == 0 ? glists.faces : kind == 1 ? glists.edges : glists.nodes;
         (void)nface;
         (void)nedge;
         for_groups(ents, [&](size_t i, size_t j) {
@@ -390,60 +432,77 @@ void assemble_coarse_matrix(const MeshTables &M, const double *sigma, double lam
             A.interior.push_back((int32_t)g);
         }
     A.n = (int64_t)A.interior.size();
-    struct Trip {
-        int32_t r, c;
-        double v;
-    };
-    std::vector<Trip> trips;
-    trips.reserve((size_t)M.ncells * N * N);
+    // row by row (rows are independent): the cells around the row's node in ascending order, their 4 x 4 / 3 x 3
+    // element matrices' row, columns sorted, duplicates summed in that fixed order
     const double volf = dim == 3 ? 1.0 / 6.0 : 0.5;
     const double massf = dim == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
-    for (int64_t c = 0; c < M.ncells; ++c) {
-        const double *Ji = &M.jinv[(size_t)c * dim * dim];
-        const double *sg = &sigma[(size_t)c * dim];
-        const int32_t *el = &M.cells[c * N];
-        double vol = M.detj[c] * volf;
-        // gradients = Jinv * refgrads (src/cell_values.jl:117)
-        double g[3][4];
-        for (int a = 0; a < dim; ++a) {
-            double s = 0.0;
-            for (int k = 0; k < dim; ++k) {
-                g[a][k + 1] = Ji[a + dim * k];
-                s += Ji[a + dim * k];
+    std::vector<int32_t> rowlen(A.n, 0);
+    struct CV {
+        int32_t c;
+        double v;
+    };
+    auto row_entries = [&](int64_t r, std::vector<CV> &buf) {
+        buf.clear();
+        const int32_t gnode = A.interior[r];
+        for (int32_t q = M.node_all_ptr[gnode]; q < M.node_all_ptr[gnode + 1]; ++q) {
+            const int64_t c = M.node_all_ent[q] >> 3;
+            const int i = M.node_all_ent[q] & 7;
+            const double *Ji = &M.jinv[(size_t)c * dim * dim];
+            const double *sg = &sigma[(size_t)c * dim];
+            const int32_t *el = &M.cells[c * N];
+            const double vol = M.detj[c] * volf;
+            // gradients = Jinv * refgrads (src/cell_values.jl:117)
+            double g[3][4];
+            for (int a = 0; a < dim; ++a) {
+                double s = 0.0;
+                for (int k = 0; k < dim; ++k) {
+                    g[a][k + 1] = Ji[a + dim * k];
+                    s += Ji[a + dim * k];
+                }
+                g[a][0] = -s;
             }
-            g[a][0] = -s;
-        }
-        for (int i = 0; i < N; ++i) {
-            int32_t ri = A.node2int[el[i]];
-            if (ri < 0) continue;
             for (int j = 0; j < N; ++j) {
-                int32_t cj = A.node2int[el[j]];
+                const int32_t cj = A.node2int[el[j]];
                 if (cj < 0) continue;
                 double k = 0.0;
                 for (int a = 0; a < dim; ++a) k += g[a][i] * sg[a] * g[a][j];
-                double v = vol * (k + lambda * massf * (i == j ? 2.0 : 1.0));
-                trips.push_back({ri, cj, v});
+                buf.push_back({cj, vol * (k + lambda * massf * (i == j ? 2.0 : 1.0))});
             }
         }
-    }
-    std::sort(trips.begin(), trips.end(), [](const Trip &a, const Trip &b) {
-        return a.r != b.r ? a.r < b.r : a.c < b.c;
+        std::stable_sort(buf.begin(), buf.end(), [](const CV &x, const CV &y) { return x.c < y.c; });
+        size_t w = 0;
+        for (size_t q = 0; q < buf.size();) {
+            size_t e = q;
+            double s = 0.0;
+            while (e < buf.size() && buf[e].c == buf[q].c) s += buf[e++].v;
+            buf[w++] = {buf[q].c, s};
+            q = e;
+        }
+        buf.resize(w);
+    };
+    parallel_for(A.n, [&](int64_t r0, int64_t r1) {
+        std::vector<CV> buf;
+        for (int64_t r = r0; r < r1; ++r) {
+            row_entries(r, buf);
+            rowlen[r] = (int32_t)buf.size();
+        }
     });
     A.rowptr.assign(A.n + 1, 0);
-    A.colidx.clear();
-    A.val.clear();
+    for (int64_t r = 0; r < A.n; ++r) A.rowptr[r + 1] = A.rowptr[r] + rowlen[r];
+    A.colidx.resize(A.rowptr[A.n]);
+    A.val.resize(A.rowptr[A.n]);
     A.diag.assign(A.n, 0.0);
-    for (size_t q = 0; q < trips.size();) {
-        size_t e = q;
-        double s = 0.0;
-        while (e < trips.size() && trips[e].r == trips[q].r && trips[e].c == trips[q].c) s += trips[e++].v;
-        A.colidx.push_back(trips[q].c);
-        A.val.push_back(s);
-        A.rowptr[trips[q].r + 1] += 1;
-        if (trips[q].r == trips[q].c) A.diag[trips[q].r] = s;
-        q = e;
-    }
-    for (int64_t r = 0; r < A.n; ++r) A.rowptr[r + 1] += A.rowptr[r];
+    parallel_for(A.n, [&](int64_t r0, int64_t r1) {
+        std::vector<CV> buf;
+        for (int64_t r = r0; r < r1; ++r) {
+            row_entries(r, buf);
+            for (size_t q = 0; q < buf.size(); ++q) {
+                A.colidx[A.rowptr[r] + q] = buf[q].c;
+                A.val[A.rowptr[r] + q] = buf[q].v;
+                if (buf[q].c == (int32_t)r) A.diag[r] = buf[q].v;
+            }
+        }
+    });
 }
 
 }  // namespace hmg

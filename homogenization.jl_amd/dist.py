@@ -213,8 +213,20 @@ def block_shape(world: int, dim: int = 3):
     return tuple(shape)
 
 
-def block_owner(base: api.Mesh, blocks, width, origin):
-    """owner[c] = index of the width^d block that contains the centre of cell c."""
+def block_owner(base: api.Mesh, blocks, width, origin, native: bool = True):
+    """owner[c] = index of the width^d block that contains the centre of cell c (native: the library's threaded host
+    code, hmg_block_owner; False: the numpy statement of the same rule)."""
+    if native:
+        dim = base.dim
+        nodes = np.ascontiguousarray(base.nodes, dtype=np.float64)
+        cells = np.ascontiguousarray(base.elements, dtype=np.int64)
+        bl = np.ascontiguousarray(blocks, dtype=np.int64)
+        org = np.ascontiguousarray(origin, dtype=np.float64)
+        owner = np.empty(cells.shape[0], dtype=np.int32)
+        L.check(L.load().hmg_block_owner(dim, nodes.shape[0], nodes.ctypes.data_as(L.p_f64), cells.shape[0],
+                                         cells.ctypes.data_as(L.p_i64), bl.ctypes.data_as(L.p_i64), float(width),
+                                         org.ctypes.data_as(L.p_f64), owner.ctypes.data_as(L.p_i32)))
+        return owner
     c = driver._centers(base) - np.asarray(origin, dtype=np.float64)
     idx = np.minimum((c // width).astype(np.int64), np.array(blocks) - 1)
     owner = np.zeros(c.shape[0], dtype=np.int64)
@@ -233,7 +245,7 @@ def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int
     blocks = block_shape(world, 3)
     shape = tuple(width * b for b in blocks)
     origin = tuple(-s / 2.0 for s in shape)
-    base = driver.order_nodes_and_elements_by_magnitude(driver.box_mesh(api.Tet64, shape, origin=origin))
+    base = driver.checkerboard_mesh(api.Tet64, shape, origin=origin, transposed_lookup=False)
     rng = np.random.default_rng(seed)
     sgrid = np.where(rng.random(shape + (3,)) < 0.5, values[0], values[1])
     cond = driver.conductivity_per_element(base, sgrid, tuple(1.0 - o for o in origin))
@@ -271,7 +283,7 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
     total_radius = box_radius + boundary_layer
     width = 2 * total_radius
     origin = (-float(total_radius),) * dim
-    base = driver.order_nodes_and_elements_by_magnitude(driver.hypercube(eltype, width, origin=origin))
+    base = driver.checkerboard_mesh(eltype, width, origin=origin, transposed_lookup=True)
     if sigma_grid is None:
         sigma_grid = driver.generate_conductivity(dim, width, seed, values)
     cond = driver.conductivity_per_element(base, sigma_grid, (total_radius + 1.0,) * dim)

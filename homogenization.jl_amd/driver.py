@@ -66,6 +66,29 @@ def box_mesh(eltype, shape, scale=1.0, origin=None) -> Mesh:
     return Mesh(nodes, (np.sort(cells, axis=1) + 1).astype(np.int64))
 
 
+def checkerboard_mesh(eltype, shape, origin=None, transposed_lookup=None, ordered: bool = True) -> Mesh:
+    """`hypercube` / `box_mesh` (+ `order_nodes_and_elements_by_magnitude` if `ordered`) by the library's threaded host
+    code (hmg_checkerboard_mesh): the same arrays as the numpy functions here, which stay as the readable statement
+    of the rule and as the test reference.  transposed_lookup: None = like `hypercube` for cubes, like `box_mesh` else."""
+    import ctypes
+    from . import _lib as L
+    lib = L.load()
+    dim = api._dim_of(eltype)
+    shape = np.ascontiguousarray([int(v) for v in (shape if np.ndim(shape) else (shape,) * dim)], dtype=np.int64)
+    assert shape.size == dim
+    origin = np.ones(dim) if origin is None else np.ascontiguousarray(origin, dtype=np.float64)
+    if transposed_lookup is None:
+        transposed_lookup = bool(np.all(shape == shape[0]))
+    nn, nc = ctypes.c_int64(), ctypes.c_int64()
+    L.check(lib.hmg_checkerboard_mesh_size(dim, shape.ctypes.data_as(L.p_i64), ctypes.byref(nn), ctypes.byref(nc)))
+    nodes = np.empty((nn.value, dim), dtype=np.float64)
+    cells = np.empty((nc.value, dim + 1), dtype=np.int64)
+    L.check(lib.hmg_checkerboard_mesh(dim, shape.ctypes.data_as(L.p_i64), origin.ctypes.data_as(L.p_f64),
+                                      1 if transposed_lookup else 0, 1 if ordered else 0,
+                                      nodes.ctypes.data_as(L.p_f64), cells.ctypes.data_as(L.p_i64)))
+    return Mesh(nodes, cells)
+
+
 def _infnorm(a):
     return np.abs(a).max(axis=-1)
 
@@ -115,8 +138,23 @@ def generate_conductivity(dim: int, n: int, seed: int, values=(1.0, 9.0)):
     return np.where(rng.random((n,) * dim + (dim,)) < 0.5, values[0], values[1])
 
 
-def conductivity_per_element(mesh: Mesh, sigma_grid, offset):
-    """ref: src/examples/homogenized_coefficients.jl:494-503"""
+def conductivity_per_element(mesh: Mesh, sigma_grid, offset, native: bool = True):
+    """ref: src/examples/homogenized_coefficients.jl:494-503 (native: the library's threaded host code; False: numpy)"""
+    if native:
+        from . import _lib as L
+        dim = mesh.dim
+        nodes = np.ascontiguousarray(mesh.nodes, dtype=np.float64)
+        cells = np.ascontiguousarray(mesh.elements, dtype=np.int64)
+        sg = np.ascontiguousarray(sigma_grid, dtype=np.float64)
+        assert sg.ndim == dim + 1 and sg.shape[-1] == dim
+        gs = np.ascontiguousarray(sg.shape[:dim], dtype=np.int64)
+        off = np.ascontiguousarray(offset, dtype=np.float64)
+        out = np.empty((cells.shape[0], dim), dtype=np.float64)
+        L.check(L.load().hmg_conductivity_per_element(dim, nodes.shape[0], nodes.ctypes.data_as(L.p_f64), cells.shape[0],
+                                                      cells.ctypes.data_as(L.p_i64), gs.ctypes.data_as(L.p_i64),
+                                                      sg.ctypes.data_as(L.p_f64), off.ctypes.data_as(L.p_f64),
+                                                      out.ctypes.data_as(L.p_f64)))
+        return out
     idx = np.trunc(_centers(mesh) + np.asarray(offset, dtype=np.float64)).astype(np.int64) - 1
     return np.ascontiguousarray(sigma_grid[tuple(idx[:, a] for a in range(mesh.dim))])
 
@@ -132,9 +170,7 @@ def checkerboard_problem(ctx, eltype, width: int, levels: int, seed: int = 0, va
     dim = api._dim_of(eltype)
     if origin is None:
         origin = (-width / 2.0,) * dim
-    base = hypercube(eltype, width, origin=origin)
-    if ordered:
-        base = order_nodes_and_elements_by_magnitude(base)
+    base = checkerboard_mesh(eltype, width, origin=origin, transposed_lookup=True, ordered=ordered)
     sgrid = generate_conductivity(dim, width, seed, values)
     cond = conductivity_per_element(base, sgrid, tuple(1.0 - o for o in origin))
     implicit = api.ImplicitFineGrid(ctx, base, levels)
@@ -172,7 +208,7 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     boundary_layer = compute_boundary_layer(lam, n)
     total_radius = box_radius + boundary_layer
     width = 2 * total_radius
-    base = order_nodes_and_elements_by_magnitude(hypercube(eltype, width, origin=(-float(total_radius),) * dim))
+    base = checkerboard_mesh(eltype, width, origin=(-float(total_radius),) * dim, transposed_lookup=True)
     if sigma_grid is None:
         sigma_grid = generate_conductivity(dim, width, seed, values)
     cond = conductivity_per_element(base, sigma_grid, (total_radius + 1.0,) * dim)

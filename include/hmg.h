@@ -209,6 +209,26 @@ int hmg_comm_sum_host(hmg_ctx *ctx, double *vals, int count);
 int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
                               const int64_t *cells, const int32_t *owner, int rank, int nranks, hmg_grid **out);
 
+/* ---- host-side problem synthesis (threaded; HMG_SETUP_THREADS, default: all cores up to 16) -------------------------
+ * hypercube(ElT, n; origin) + order_nodes_and_elements_by_magnitude (src/tet/generate_grid.jl:6-45,
+ * src/tri/generate_grid.jl:6-35, src/examples/homogenized_coefficients.jl:21-28) in one call: a box of shape[] unit
+ * cubes (6 tetrahedra / 2 triangles each), node ids with the last coordinate fastest.  transposed_lookup = 1 reproduces
+ * the reference's corner lookup (first-index-fastest id table, cubes only: the geometry comes out transposed, as in
+ * the reference); 0 keeps node id and coordinates aligned (boxes for multi-GPU weak scaling).  ordered = 1 sorts nodes
+ * and cells by infinity norm (stable) so that every centred sub-box is a prefix.  cells: 1-based ascending tuples. */
+int hmg_checkerboard_mesh_size(int dim, const int64_t *shape, int64_t *nnodes, int64_t *ncells);
+int hmg_checkerboard_mesh(int dim, const int64_t *shape, const double *origin, int transposed_lookup, int ordered,
+                          double *coords /* dim*nnodes */, int64_t *cells /* (dim+1)*ncells */);
+/* conductivity_per_element(mesh, sigma, offset) (src/examples/homogenized_coefficients.jl:494-503): sigma[c] =
+ * sigma_grid[trunc(centre_c + offset) - 1]; sigma_grid: grid_shape[0] x .. x grid_shape[dim-1] x dim, C order */
+int hmg_conductivity_per_element(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells,
+                                 const int64_t *grid_shape, const double *sigma_grid, const double *offset, double *sigma);
+
+/* owner[c] = row-major index of the width^dim block (blocks[] of them per axis, counted from origin) that holds the
+ * centre of cell c -- the ownership partition of the multi-GPU runs (halves / quadrants / octants about the origin) */
+int hmg_block_owner(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells,
+                    const int64_t *blocks, double width, const double *origin, int32_t *owner);
+
 #ifdef __cplusplus
 }
 #endif

@@ -392,3 +392,59 @@ def test_partitioned_shrink_host_tables(oracle):
         np.testing.assert_array_equal(g.table_i32("dmask"), want[after])
         seen.append(after)
     np.testing.assert_array_equal(np.sort(np.concatenate(seen)), np.arange(ne_keep))
+
+
+@pytest.mark.parametrize("dim,shape,origin,transposed", [(3, (6, 6, 6), (-3.0, -3.0, -3.0), True), (2, (9, 9), (-4.5, -4.5), True),
+                                                         (3, (4, 6, 2), (-2.0, -3.0, -1.0), False), (2, (5, 3), (1.0, 1.0), False),
+                                                         (3, (5, 5, 5), (1.0, 1.0, 1.0), True)])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_native_checkerboard_synthesis_equals_numpy_statement(dim, shape, origin, transposed, ordered):
+    """hmg_checkerboard_mesh / hmg_conductivity_per_element (threaded host C++) against the numpy restatement of
+    hypercube / order_nodes_and_elements_by_magnitude / conductivity_per_element
+    (src/tet/generate_grid.jl:6-45, src/examples/homogenized_coefficients.jl:21-28, 494-503): identical arrays."""
+    import homogenization_jl_amd as hmg
+    from homogenization_jl_amd import driver
+    tag = hmg.Tet64 if dim == 3 else hmg.Tri64
+    ref = driver.hypercube(tag, shape[0], origin=origin) if transposed else driver.box_mesh(tag, shape, origin=origin)
+    if ordered:
+        ref = driver.order_nodes_and_elements_by_magnitude(ref)
+    got = driver.checkerboard_mesh(tag, shape, origin=origin, transposed_lookup=transposed, ordered=ordered)
+    np.testing.assert_array_equal(got.nodes, ref.nodes)
+    np.testing.assert_array_equal(got.elements, ref.elements)
+    rng = np.random.default_rng(1)
+    sg = rng.choice([1.0, 9.0], size=tuple(shape) + (dim,))
+    off = tuple(1.0 - o for o in origin)
+    np.testing.assert_array_equal(driver.conductivity_per_element(got, sg, off, native=True),
+                                  driver.conductivity_per_element(ref, sg, off, native=False))
+
+
+def test_setup_threads_do_not_change_the_tables(monkeypatch):
+    """The threaded sorts of the table builders are total orders: interface lists, masks and the level-1 matrix pattern
+    are the same whatever the thread count (values of the matrix: summed in a fixed order)."""
+    import os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import homogenization_jl_amd as hmg
+from homogenization_jl_amd import driver
+base = driver.checkerboard_mesh(hmg.Tet64, 24, origin=(-12.0,) * 3, transposed_lookup=True)
+sg = driver.generate_conductivity(3, 24, 0)
+cond = driver.conductivity_per_element(base, sg, (13.0,) * 3)
+g = hmg.ImplicitFineGrid(None, base, 3)
+g.set_operator(cond, 1.0)
+g.coarse_setup()
+h = hashlib.sha256()
+for name in ("face_pairs", "edge_ptr", "edge_ent", "node_ptr", "node_ent", "node_first", "dmask", "dupmask", "mult",
+             "coarse_rowptr", "coarse_colidx"):
+    h.update(g.table_i32(name).tobytes())
+h.update(g.table_f64("coarse_val").tobytes())
+h.update(base.nodes.tobytes()); h.update(base.elements.tobytes())
+print(h.hexdigest())
+''' % ROOT
+    out = []
+    for t in ("1", "8"):
+        env = dict(os.environ, HMG_SETUP_THREADS=t)
+        out.append(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip().splitlines()[-1])
+    assert out[0] == out[1]
