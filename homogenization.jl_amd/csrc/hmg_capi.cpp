@@ -108,6 +108,7 @@ struct hmg_ctx {
     Launch L{};
     int coarse_maxit = 5000;
     int coarse_check = 25;
+    bool coarse_probe = true;   // budgeted level-1 solves leave a probe behind (off: stream-capture experiments)
     double coarse_rtol = 1e-13;
     // in-library communicator (one rank per GPU, RCCL over xGMI): hmg_comm_init
     ncclComm_t comm = nullptr;
@@ -966,7 +967,7 @@ void coarse_pcg(hmg_grid *g)
     // Convergence is decided on the device: k_coarse_pupdate sets a flag once r.r <= rtol^2 b.b and every kernel of
     // the later iterations returns at once, so a fixed number of iterations can be enqueued without a host round trip.
     // The first solve after a (re)assembly finds that number the slow way (a look every coarse_check iterations);
-    // later solves enqueue 1.5 x the largest count seen + coarse_check, leave a probe (flag, count, r.r) behind in pinned
+    // later solves enqueue the largest count seen + 1/8 (at least 8), leave a probe (flag, count, r.r) behind in pinned
     // memory and return; the probe is checked at the next solve (or when the iteration count is asked for).
     hmg_ctx *c = g->ctx;
     const Launch &L = c->L;
@@ -1001,7 +1002,7 @@ void coarse_pcg(hmg_grid *g)
     if (g->coarse_budget > 0) {
         iterate(g->coarse_budget);
         pr.budget = g->coarse_budget;
-        probe();
+        if (c->coarse_probe) probe();
         return;
     }
     int it = 0;
@@ -1020,7 +1021,7 @@ void coarse_pcg(hmg_grid *g)
             throw std::runtime_error("coarse PCG: no convergence to coarse_rtol within coarse_maxit iterations");
     }
     g->coarse_last_it = (int)pr.h[1];
-    g->coarse_budget = std::min(c->coarse_maxit, (3 * std::max(g->coarse_last_it, 1)) / 2 + c->coarse_check);
+    g->coarse_budget = std::min(c->coarse_maxit, g->coarse_last_it + std::max(8, g->coarse_last_it / 8));
 }
 
 // Blocks until the probe of the last budgeted solve has landed and judges it.
@@ -1039,7 +1040,7 @@ void coarse_probe_wait(hmg_grid *g)
                                  std::to_string(pr.budget) + " iterations enqueued for it");
     }
     g->coarse_budget = std::max(g->coarse_budget,
-                                std::min(g->ctx->coarse_maxit, (3 * std::max(g->coarse_last_it, 1)) / 2 + g->ctx->coarse_check));
+                                std::min(g->ctx->coarse_maxit, g->coarse_last_it + std::max(8, g->coarse_last_it / 8)));
 }
 
 void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
@@ -1378,6 +1379,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->coarse_maxit = (int)value;
     else if (n == "coarse_check")
         ctx->coarse_check = std::max<int>(1, (int)value);
+    else if (n == "coarse_probe")
+        ctx->coarse_probe = value != 0;
     else if (n == "fuse_cg")
         ctx->fuse_cg_default = value != 0;
     else if (n == "fold_x")

@@ -696,16 +696,33 @@ void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pa
 __global__ void __launch_bounds__(256)
 k_iface_faces(const int32_t *__restrict__ pairs, int64_t npairs, int nfi, int off_face, int ld, double *x)
 {
+    // one wave per shared face; all loads of (up to) 8 x 64 DOFs of both copies in flight before the first store
+    constexpr int U = 8;
     const int lane = threadIdx.x & 63;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; p < npairs; p += nw) {
         const int32_t ca = pairs[3 * p], cb = pairs[3 * p + 1], lf = pairs[3 * p + 2];
         double *a = x + (int64_t)ca * ld + off_face + (lf & 15) * nfi;
         double *b = x + (int64_t)cb * ld + off_face + (lf >> 4) * nfi;
-        for (int k = lane; k < nfi; k += 64) {
-            const double s = a[k] + b[k];   // (0 + a) + b, ascending cell order
-            a[k] = s;
-            b[k] = s;
+        for (int k0 = 0; k0 < nfi; k0 += U * 64) {
+            double va[U], vb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * 64 + lane;
+                if (k < nfi) {
+                    va[u] = a[k];
+                    vb[u] = b[k];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * 64 + lane;
+                if (k < nfi) {
+                    const double s = va[u] + vb[u];   // (0 + a) + b, ascending cell order
+                    a[k] = s;
+                    b[k] = s;
+                }
+            }
         }
     }
 }
@@ -741,8 +758,7 @@ void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &me
 {
     const int cap = L.num_cu * 8;
     if (which != 1 && lv.dim == 3 && lv.nfi > 0 && mesh.nfacepairs > 0) {
-        int64_t blocks = (mesh.nfacepairs + 3) / 4;
-        if (blocks > cap * 4) blocks = cap * 4;
+        const int64_t blocks = (mesh.nfacepairs + 3) / 4;     // one wave per pair, blocks dispatched in pair order
         hipLaunchKernelGGL(k_iface_faces, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.face_pairs,
                            mesh.nfacepairs, lv.nfi, lv.off_face, lv.ld, x);
         check_launch();

@@ -184,6 +184,21 @@ void build_from_cells0(MeshTables &M, EntLists *keep = nullptr)
                 throw std::runtime_error("base mesh: a face is shared by more than two cells");
         });
         if (keep) keep->faces.swap(faces);
+        // pairs in ascending order of their first cell: consecutive wavefronts of the face kernel then walk the level
+        // vector front to back (the key order above follows the node numbering instead)
+        {
+            struct P3 {
+                int32_t a, b, l;
+            };
+            std::vector<P3> pr(M.face_pairs.size() / 3);
+            for (size_t q = 0; q < pr.size(); ++q) pr[q] = {M.face_pairs[3 * q], M.face_pairs[3 * q + 1], M.face_pairs[3 * q + 2]};
+            parallel_sort(pr, [](const P3 &x, const P3 &y) { return x.a != y.a ? x.a < y.a : x.b != y.b ? x.b < y.b : x.l < y.l; });
+            for (size_t q = 0; q < pr.size(); ++q) {
+                M.face_pairs[3 * q] = pr[q].a;
+                M.face_pairs[3 * q + 1] = pr[q].b;
+                M.face_pairs[3 * q + 2] = pr[q].l;
+            }
+        }
     }
     {
         auto edges = list_entities(M, 1);

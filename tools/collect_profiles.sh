@@ -1,10 +1,11 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats and PMC passes over the default bench
-# workload.  Output under gpurun_out/prof_r01/; tools/summarize_profiles.py turns it into profiles/.
+# workload.  bash tools/collect_profiles.sh <tag>: output under gpurun_out/prof_<tag>/; tools/summarize_profiles.py <tag>
+# turns it into profiles/<tag>_*.
 set -e
 cd /tmp; export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof_r01; rm -rf $O; mkdir -p $O
-CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r02}; O=$R/gpurun_out/prof_$T; rm -rf $O; mkdir -p $O
+CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-time-to-tolerance"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMD > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $CMD > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $CMD > $O/pmc_write.log 2>&1

@@ -2,9 +2,9 @@
 """Condenses gpurun_out/prof_r01 (tools/collect_profiles.sh) into the tracked files under profiles/."""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "gpurun_out", "prof_r01")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(dst, exist_ok=True)
 
 
@@ -17,7 +17,7 @@ stats = one("trace/*/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(dst, f"{tag}_vcycle_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline (3 V-cycles + setup)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-time-to-tolerance (3 V-cycles + setup)\n")
     f.write("name,calls,total_ms,avg_us,min_us,max_us,pct\n")
     for r in rows:
         f.write(f"\"{r['Name']}\",{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e3:.2f},"
