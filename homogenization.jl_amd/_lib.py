@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhmg_hip.so")
+LIB_PATH = os.environ.get("HMG_LIB_PATH") or os.path.join(_HERE, "libhmg_hip.so")   # (HMG_LIB_PATH: A/B runs of two builds)
 
 c_i64 = ctypes.c_int64
 c_f64 = ctypes.c_double

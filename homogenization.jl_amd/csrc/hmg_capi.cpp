@@ -343,8 +343,10 @@ static void upload_levels(hmg_grid *g)
             // register-blocked interior of k_apply (interior_block in hmg_kernels.hip): every R-th interior k-plane,
             // all its interior (i,j) in lattice order; R = 6 makes the 4495 interior nodes of level 6 945 entries,
             // one pass of a 1024-thread workgroup
-            if (T.dim == 3 && T.nint > 0 && T.m <= 63 && T.nf > 2048 && sizeof(double) * (size_t)(T.nf + 512) <= 160 * 1024) {
-                const int R = 6, m = T.m;
+            // (level 5: R = 4, 152 entries for its 256-thread workgroup)
+            if (T.dim == 3 && T.nint > 0 && T.m <= 63 && (T.nf > 2048 || (T.nf > 256 && T.nf <= 1024)) &&
+                sizeof(double) * (size_t)(T.nf + 512) <= 160 * 1024) {
+                const int R = T.nf > 2048 ? 6 : 4, m = T.m;
                 std::vector<int32_t> slot_of_L(T.nf, -1);
                 for (int q = 0; q < T.nf; ++q) slot_of_L[(size_t)(T.meta[q] & 0xffffu)] = q;
                 auto tri = [](int n) { return (n + 1) * (n + 2) / 2; };
@@ -378,7 +380,8 @@ static void upload_levels(hmg_grid *g)
                 // 3 runs of 64 for corners + edges)
                 static const uint32_t absent[4] = {1u << 8 | 1u << 10 | 1u << 12 | 1u << 14, 1u << 4 | 1u << 6 | 1u << 7 | 1u << 13,
                                                    1u << 2 | 1u << 3 | 1u << 9 | 1u << 14, 1u << 1 | 1u << 5 | 1u << 11 | 1u << 13};
-                bool ok = T.nface == 4 && T.nfi <= 512 && T.off_face <= 192 && (int)bw.size() <= 15 * 64;
+                const int nw = T.nf > 2048 ? 16 : 4;     // waves of the workgroup that runs this level
+                bool ok = T.nface == 4 && T.nfi <= 128 * std::max(nw / 4, 1) && T.nei <= 64 && (int)bw.size() <= (nw - 1) * 64;
                 for (int f = 0; ok && f < 4; ++f)
                     for (int d = 0; d < T.ndir; ++d) {
                         bool zero = true;

@@ -181,26 +181,41 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const int nsurf = lv.off_int;
     // (pos32 / sweep32 / sweep_slot carry TABLE_PAD entries of padding -- zero words, slot 0xffff -- so the
     //  two-ahead prefetch needs no bounds checks and both loops have a wave-uniform trip count)
-    // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the last 6 waves take one
-    // edge each, the last wave the corners instead of an interior block -- the 945 blocks of level 6 fill waves 0..14.
-    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, FI = 2;
+    // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the edges are dealt to the
+    // waves from the last one backwards (NE per wave: 1 of 16 waves, 2 of 4), the last wave takes the corners instead
+    // of an interior block -- the 945 blocks of level 6 fill waves 0..14, the 152 of level 5 waves 0..2.
+    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, FI = 2, NE = NW >= 6 ? 1 : 2;
     const int wave = tid >> 6, lane = tid & 63;
     const int face = wave / WPF, ft0 = (wave % WPF) * (FI * 64);
-    const int edge = wave - (NW - 6), ebase = lv.off_edge + (edge < 0 ? 0 : edge) * lv.nei;
-    uint32_t fw[FI] = {0u, 0u}, ew[1] = {0u}, cw = 0u;
+    int edge[NE], ebase[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        edge[q] = NW - 1 - wave + q * NW;
+        if (edge[q] >= lv.nedge) edge[q] = -1;
+        ebase[q] = lv.off_edge + (edge[q] < 0 ? 0 : edge[q]) * lv.nei;
+    }
+    uint32_t fw[FI] = {0u, 0u}, ew[NE][1], cw = 0u;
     uint32_t p0 = 0u, p1 = 0u;
-    double wv = 0.0;                 // RB: lane d: interior weight d; lane 16 + d: this wave's face; lane 32 + d: its edge
+    double wv = 0.0;                 // RB: lane d: interior weight d; lane 16 + d: this wave's face; lane 32 + 16 q + d: its edge q
     if (RB) {
 #pragma unroll
         for (int q = 0; q < FI; ++q) {
             const int ti = ft0 + q * 64 + lane;
             if (ti < lv.nfi) fw[q] = lv.pos32[lv.off_face + face * lv.nfi + ti];
         }
-        if (edge >= 0 && lane < lv.nei) ew[0] = lv.pos32[ebase + lane];
+#pragma unroll
+        for (int q = 0; q < NE; ++q) ew[q][0] = edge[q] >= 0 && lane < lv.nei ? lv.pos32[ebase[q] + lane] : 0u;
         if (wave == NW - 1 && lane < lv.ncorner) cw = lv.pos32[lane];
         // class rows (L2-resident table) x the cell's 7 scales
-        const int row = lane < 15 ? lane : (lane >= 16 && lane < 31) ? (1 + face) * NDIR + lane - 16
-                        : (lane >= 32 && lane < 47 && edge >= 0) ? (1 + lv.nface + edge) * NDIR + lane - 32 : 0;
+        int row = 0;
+        if (lane < 15)
+            row = lane;
+        else if (lane >= 16 && lane < 31)
+            row = (1 + face) * NDIR + lane - 16;
+        else if (lane >= 32 && lane < 47 && edge[0] >= 0)
+            row = (1 + lv.nface + edge[0]) * NDIR + lane - 32;
+        else if (NE > 1 && lane >= 48 && lane < 63 && edge[NE - 1] >= 0)
+            row = (1 + lv.nface + edge[NE - 1]) * NDIR + lane - 48;
         double c7[NTERM], sc7[NTERM];
 #pragma unroll
         for (int t = 0; t < NTERM; ++t) c7[t] = lv.ctab[(size_t)row * NTERM + t];
@@ -270,18 +285,21 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 face_items<2, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
             else
                 face_items<3, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
-            if (edge >= 0) {
-                const int eb = lv.nface + edge;
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                if (edge[q] < 0) continue;
+                const int eb = lv.nface + edge[q];
                 const bool edir = (dm >> eb) & 1u;
                 const double emult = (double)(((eb < 4 ? mq[0] : eb < 8 ? mq[1] : mq[2]) >> (8 * (eb & 3))) & 0xffu);
                 const double nop1[1] = {0.0};
-                switch (edge) {
-                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, 32, xs, m, lv.nei, ebase, 0, ew, edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                const int wl = 32 + 16 * q;
+                switch (edge[q]) {
+                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
                 }
             }
             if (wave == NW - 1 && lane < lv.ncorner) surface_node(lane, cw);
@@ -617,8 +635,13 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         launch_apply_generic<DIM, 64, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 192 && nf <= 192)
         launch_apply_generic<DIM, 192, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
-    else if (nt <= 256 && nf <= 1024)
-        launch_apply_generic<DIM, 256, 4, FUSED, 0, WD>(L, lv, mesh, a, lds);
+    else if (nt <= 256 && nf <= 1024) {
+        if (DIM == 3 && lv.blk_R == 4 && lv.nblk <= 192 && lv.nfi <= 128 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 &&
+            !L.apply_unblocked)
+            launch_apply_generic<DIM, 256, 4, FUSED, DIM == 3 ? 4 : 0, WD>(L, lv, mesh, a, lds);
+        else
+            launch_apply_generic<DIM, 256, 4, FUSED, 0, WD>(L, lv, mesh, a, lds);
+    }
     else if (nt <= 256)
         launch_apply_generic<DIM, 256, 8, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 640) {
