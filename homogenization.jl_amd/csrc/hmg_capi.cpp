@@ -101,6 +101,7 @@ struct hmg_ctx {
     bool swap_rp = true;  // V-cycle: step 0 of a smoother takes r itself as p (pointer exchange), see smooth()
     bool fold_prolong = true;   // V-cycle: prolongation folded into the post-smoother's first residual
     bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
+    bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -138,7 +139,7 @@ struct hmg_grid {
     MeshTables mesh_full, mesh;
     bool shrunk = false;
     MeshDev md{};
-    DevBuf<int32_t> d_cells, d_face_pairs, d_edge_ptr, d_edge_ent, d_node_ptr, d_node_ent, d_node_first;
+    DevBuf<int32_t> d_cells, d_face_pairs, d_face_partner, d_edge_ptr, d_edge_ent, d_node_ptr, d_node_ent, d_node_first;
     DevBuf<uint16_t> d_dmask, d_dupmask;
     DevBuf<uint8_t> d_mult;
     DevBuf<double> d_blockpart;
@@ -254,6 +255,15 @@ void upload_mesh(hmg_grid *g)
     hipStream_t s = g->ctx->stream;
     g->d_cells.upload(M.cells, s);
     g->d_face_pairs.upload(M.face_pairs, s);
+    {
+        std::vector<int32_t> fp((size_t)M.ncells * 4, -1);
+        for (size_t q = 0; q + 2 < M.face_pairs.size(); q += 3) {
+            const int32_t ca = M.face_pairs[q], cb = M.face_pairs[q + 1], la = M.face_pairs[q + 2] & 15, lb = M.face_pairs[q + 2] >> 4;
+            fp[(size_t)ca * 4 + la] = (cb << 2) | lb;
+            fp[(size_t)cb * 4 + lb] = (ca << 2) | la;
+        }
+        g->d_face_partner.upload(fp, s);
+    }
     g->d_edge_ptr.upload(M.edge_ptr, s);
     g->d_edge_ent.upload(M.edge_ent, s);
     g->d_node_ptr.upload(M.node_ptr, s);
@@ -274,6 +284,7 @@ void upload_mesh(hmg_grid *g)
     d.nnodes = M.nnodes;
     d.cells = g->d_cells.p;
     d.face_pairs = g->d_face_pairs.p;
+    d.face_partner = g->d_face_partner.p;
     d.nfacepairs = (int64_t)M.face_pairs.size() / 3;
     d.edge_ptr = g->d_edge_ptr.p;
     d.edge_ent = g->d_edge_ent.p;
@@ -672,9 +683,9 @@ void restrict_level(hmg_grid *g, int level_fine, const double *rf, double *bc)
     launch_restrict(g->ctx->L, fine, coarse, g->md.ncells, rf, bc);
 }
 
-void interface_sum(hmg_grid *g, const LevelDev &lv, double *x)
+void interface_sum(hmg_grid *g, const LevelDev &lv, double *x, bool faces = true)
 {
-    launch_interface_sum(g->ctx->L, lv, g->md, x);
+    launch_interface_sum(g->ctx->L, lv, g->md, x, 0, faces);
     if (g->exchange || g->ex_begin) exchange_cut(g, lv, x);
 }
 
@@ -724,7 +735,7 @@ struct TimedRegion {   // HIP-event bracket of the finest-level operator applies
 // the sum over ranks is started, then the remaining cells and interface entities are processed while it
 // is in flight.
 void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, int slot_pap, int slot_rr,
-                    bool sum_out = true)
+                    bool sum_out = true, bool faces = true)
 {
     hmg_ctx *c = g->ctx;
     const Launch &L = c->L;
@@ -771,7 +782,7 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
         launch(nullptr, 0);
         tr.stop();
         sums();
-        interface_sum(g, lv, a.out);
+        interface_sum(g, lv, a.out, faces);
         return;
     }
     need(ncut <= g->ex_cap, "exchange buffer too small for this level");
@@ -783,7 +794,7 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     if (g->md.ncells_inner > 0)                           // (an empty list must not read as "all cells")
         launch(g->md.cells_inner, g->md.ncells_inner);    // overlaps the sum over ranks
     tr.stop();
-    launch_interface_sum(L, lv, g->md, a.out, 2);
+    launch_interface_sum(L, lv, g->md, a.out, 2, faces);
     sums();
     if (g->ex_end(g->ex_user) != 0) throw std::runtime_error("exchange (end) callback failed");
     cut_pack(g, lv, a.out, 1);
@@ -881,7 +892,10 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
                 d.b_den = other;
                 return d;
             }
-            apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1);
+            // the face part of Ap's interface sum rides in the r-update below, except on the last step of a smoother
+            // whose state is handed back (Ap must then hold what the reference leaves)
+            const bool ride = g->ctx->fold_faces && lv.dim == 3 && lv.nfi > 0 && !dead && !(live_tail && i == steps - 1);
+            apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1, true, !ride);
             const double *r_in = r->d;
             if (i == 0 && swap_rp) {
                 std::swap(r->d, p->d);                                    // p now names r_0, r the spare buffer
@@ -898,7 +912,10 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
                 launch_cg_xp_update(L, x->d, p->d, r->d, n, cur, S_PAP, cur, other, 0);   // x += (rs / p.Ap) p
                 return none;
             }
-            launch_cg_rupdate(L, r_in, r->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs / p.Ap
+            if (ride)
+                launch_cg_rupdate_faces(L, lv, g->md, r_in, r->d, Ap->d, n, cur, S_PAP, other);
+            else
+                launch_cg_rupdate(L, r_in, r->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs / p.Ap
             scalar_sum(g, other, 1);
             std::swap(cur, other);
         }
@@ -970,7 +987,8 @@ void coarse_pcg(hmg_grid *g)
     // Convergence is decided on the device: k_coarse_pupdate sets a flag once r.r <= rtol^2 b.b and every kernel of
     // the later iterations returns at once, so a fixed number of iterations can be enqueued without a host round trip.
     // The first solve after a (re)assembly finds that number the slow way (a look every coarse_check iterations);
-    // later solves enqueue the largest count seen + 1/8 (at least 8), leave a probe (flag, count, r.r) behind in pinned
+    // later solves enqueue 1.5 x the largest count seen + 16 (the count moves by 10-20 % from one right-hand side to
+    // the next; a no-op iteration costs ~3 us of launches), leave a probe (flag, count, r.r) behind in pinned
     // memory and return; the probe is checked at the next solve (or when the iteration count is asked for).
     hmg_ctx *c = g->ctx;
     const Launch &L = c->L;
@@ -1024,7 +1042,7 @@ void coarse_pcg(hmg_grid *g)
             throw std::runtime_error("coarse PCG: no convergence to coarse_rtol within coarse_maxit iterations");
     }
     g->coarse_last_it = (int)pr.h[1];
-    g->coarse_budget = std::min(c->coarse_maxit, g->coarse_last_it + std::max(8, g->coarse_last_it / 8));
+    g->coarse_budget = std::min(c->coarse_maxit, g->coarse_last_it + g->coarse_last_it / 2 + 16);
 }
 
 // Blocks until the probe of the last budgeted solve has landed and judges it.
@@ -1043,7 +1061,7 @@ void coarse_probe_wait(hmg_grid *g)
                                  std::to_string(pr.budget) + " iterations enqueued for it");
     }
     g->coarse_budget = std::max(g->coarse_budget,
-                                std::min(g->ctx->coarse_maxit, g->coarse_last_it + std::max(8, g->coarse_last_it / 8)));
+                                std::min(g->ctx->coarse_maxit, g->coarse_last_it + g->coarse_last_it / 2 + 16));
 }
 
 void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
@@ -1394,6 +1412,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->fold_prolong = value != 0;
     else if (n == "lazy_dead")
         ctx->lazy_dead = value != 0;
+    else if (n == "fold_faces")
+        ctx->fold_faces = value != 0;
     else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
         ctx->timer.on = value > 0;
         ctx->timer.min_level = (int)value;

@@ -54,6 +54,7 @@ struct MeshDev {
     const int32_t *cells;        // (dim+1)*ncells
     const int32_t *face_pairs;   // 3*nfacepairs
     int64_t nfacepairs;
+    const int32_t *face_partner; // 4*ncells: partner cell << 2 | partner face of every face (-1: boundary / cut / 2D)
     const int32_t *edge_ptr, *edge_ent;
     int64_t nsharededges;
     const int32_t *node_ptr, *node_ent;
@@ -142,7 +143,9 @@ void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pa
 void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);
 
 // which: 0 everything; 1 only the cut edge / node groups; 2 everything else (faces, non-cut groups)
-void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which = 0);
+// faces = false leaves the shared faces alone (their sum then rides in launch_cg_rupdate_faces)
+void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which = 0,
+                          bool faces = true);
 void launch_mask(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which /*0 dmask,1 dupmask*/);
 void launch_restrict_slab(const Launch &L, const LevelDev &fine_rtab, const MeshDev &mesh, const SlabTables &st, int ldc,
                           const double *rf, double *bc);
@@ -167,6 +170,9 @@ void launch_cg_update(const Launch &L, double *x, double *r, const double *p, co
 // alpha = scal[s_num]/scal[s_den]; r -= alpha q; scal[s_out] = r.r
 void launch_cg_rupdate(const Launch &L, const double *r, double *rout, const double *q, int64_t n, int s_num, int s_den,
                        int s_out);
+// the same with the face part of q's interface sum taken on the fly (q unsummed on the shared faces)
+void launch_cg_rupdate_faces(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
+                             const double *q, int64_t n, int s_num, int s_den, int s_out);
 // x += (scal[a_num]/scal[a_den]) p; with_p: p = r + (scal[s_num]/scal[s_den]) p
 void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
                          int s_num, int s_den, int with_p);
