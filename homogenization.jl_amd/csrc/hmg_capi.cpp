@@ -102,6 +102,7 @@ struct hmg_ctx {
     bool fold_prolong = true;   // V-cycle: prolongation folded into the post-smoother's first residual
     bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
+    bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -826,9 +827,13 @@ struct DeferredX {
 // applied in the load phase of the first residual instead of by a separate prolongation pass.
 // With defer_x and lazy a dead last step i > 0 writes nothing at all: it forms p_i only in
 // LDS for the operator apply and the p.Ap reduction, and leaves both pending x-updates to the caller (DeferredX).
+// scratch_p (with live_tail = true): x and r are what the reference leaves, p and Ap are not -- the last p-update
+// (src/multigrid.jl:68) is skipped and Ap stays unsummed on the faces (its face sums ride in the r-update).  For the
+// post-smoother of the finest level inside hmg_vcycle: the caller reads x and r (the driver's residual norm,
+// src/examples/homogenized_coefficients.jl:286), the next smoothing_steps! starts with p <- r and Ap <- 0.
 DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
                  bool live_tail = true, bool defer_x = false, bool swap_rp = false, const hmg_vec *xcoarse = nullptr,
-                 bool lazy = false)
+                 bool lazy = false, bool scratch_p = false)
 {
     DeferredX none;
     // ref: src/multigrid.jl:46-71
@@ -894,7 +899,8 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             }
             // the face part of Ap's interface sum rides in the r-update below, except on the last step of a smoother
             // whose state is handed back (Ap must then hold what the reference leaves)
-            const bool ride = g->ctx->fold_faces && lv.dim == 3 && lv.nfi > 0 && !dead && !(live_tail && i == steps - 1);
+            const bool ride = g->ctx->fold_faces && lv.dim == 3 && lv.nfi > 0 && !dead &&
+                              !(live_tail && !scratch_p && i == steps - 1);
             apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1, true, !ride);
             const double *r_in = r->d;
             if (i == 0 && swap_rp) {
@@ -922,7 +928,7 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
         if (steps > 0) {
             // x += alpha_last p (alpha_last = rs_{s-1} / p.Ap: `other` holds rs_{s-1} after the swap) and the
             // reference's last p-update p = r + (rs_s / rs_{s-1}) p
-            launch_cg_xp_update(L, x->d, p->d, r->d, n, other, S_PAP, cur, other, 1);
+            launch_cg_xp_update(L, x->d, p->d, r->d, n, other, S_PAP, cur, other, scratch_p ? 0 : 1);
         } else {
             launch_copy_dot(L, p->d, r->d, n, cur);
             scalar_sum(g, cur, 1);
@@ -942,6 +948,7 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
         }
         launch_cg_update(L, x->d, r->d, p->d, Ap->d, n, cur, S_PAP, other);   // alpha = rs/pAp
         scalar_sum(g, other, 1);
+        if (scratch_p && i == steps - 1) return none;
         launch_cg_pupdate(L, p->d, r->d, n, other, cur);                       // beta = rs'/rs
         std::swap(cur, other);
     }
@@ -1140,7 +1147,12 @@ void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st)
 }
 
 // Up leg (src/multigrid.jl:112-115): coarse-grid correction x_k += P x_{k-1}, post-smoother.
-void vcycle_up(hmg_grid *g, int k, int steps, hmg_vec **st)
+// Inside hmg_vcycle (option lean_post) the post-smoother's dead tail is dropped as the pre-smoother's is: on the finest
+// level the caller can read x and r, so only the last p-update and the face sums of the last Ap go (scratch_p); on the
+// levels below nothing but x is read before the next visit overwrites r, p and Ap (local residual, p <- r, Ap <- 0:
+// src/multigrid.jl:46-50,104), so of the last CG step only alpha and x += alpha p are done.  x (and r on the finest
+// level) are bit-identical with the full sequence.
+void vcycle_up(hmg_grid *g, int k, int steps, hmg_vec **st, int lean = 0)
 {
     hmg_vec **cur = st + 5 * (k - 1);
     hmg_vec **nxt = st + 5 * (k - 2);
@@ -1151,10 +1163,12 @@ void vcycle_up(hmg_grid *g, int k, int steps, hmg_vec **st)
     const bool fold_p = g->ctx->fold_prolong && g->fuse_cg && apply_lds_bytes(lev(g, k)) <= 160 * 1024 &&
                         apply_lds_bytes(lev(g, k)) + sizeof(double) * (size_t)lev(g, k - 1).nf <= 80 * 1024;
     if (!fold_p) launch_prolong_add(L, lev(g, k), lev(g, k - 1), g->md.ncells, nxt[0]->d, cur[0]->d);
-    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], true, false, swap_rp, fold_p ? nxt[0] : nullptr);
+    const bool x_only = lean == 2 && steps > 0;
+    smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/!x_only, false, swap_rp, fold_p ? nxt[0] : nullptr,
+           false, /*scratch_p=*/lean == 1);
 }
 
-void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
+void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st, bool top = true)
 {
     // ref: src/multigrid.jl:73-119
     if (k == 1) {
@@ -1163,8 +1177,8 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st)
         return;
     }
     vcycle_down(g, k, steps, st);
-    vcycle(g, k - 1, steps_coarse, steps_coarse, st);
-    vcycle_up(g, k, steps, st);
+    vcycle(g, k - 1, steps_coarse, steps_coarse, st, false);
+    vcycle_up(g, k, steps, st, g->ctx->lean_post ? (top ? 1 : 2) : 0);
 }
 
 // ---- multi-GPU cut exchange -------------------------------------------------------------------
@@ -1414,6 +1428,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->lazy_dead = value != 0;
     else if (n == "fold_faces")
         ctx->fold_faces = value != 0;
+    else if (n == "lean_post")
+        ctx->lean_post = value != 0;
     else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
         ctx->timer.on = value > 0;
         ctx->timer.min_level = (int)value;
@@ -2191,7 +2207,7 @@ int hmg_vcycle_up(hmg_grid *g, int level, int steps, hmg_vec **states)
 {
     HMG_TRY
     check_two_levels(g, level, states);
-    vcycle_up(g, level, steps, states);
+    vcycle_up(g, level, steps, states, g->ctx->lean_post ? 1 : 0);   // as the finest level of hmg_vcycle
     HMG_END
 }
 

@@ -47,7 +47,11 @@ int hmg_ctx_sync(hmg_ctx *ctx);
  * folds the pre-smoother's last x-update into the local residual / lets the pre-smoother's last step write nothing
  * and folds both pending x-updates / lets CG step 0 take r itself as p by exchanging the two handles' device
  * pointers / folds the prolongation into the post-smoother's first residual -- exact savings, results unchanged;
- * 0 = the plain sequence), "coarse_maxit", "coarse_check",
+ * 0 = the plain sequence), "lean_post" (1 = default: hmg_vcycle also drops the post-smoothers' dead tails -- the last
+ * p-update and, below the top level, everything of the last CG step but x += alpha p; x of every level and r of the
+ * top level are unchanged bit for bit, p / Ap (and r below the top level) are scratch on return, as they are for the
+ * reference's own callers: the next smoothing_steps! overwrites them before reading, src/multigrid.jl:46-50;
+ * 0 = they hold what the reference leaves), "coarse_maxit", "coarse_check",
  * "time_apply"; "coarse_rtol" via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
  * kernel for cells larger than the LDS, default 70). */
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
@@ -152,7 +156,9 @@ int hmg_vcycle(hmg_grid *grid, int top_level, int steps, int steps_coarse, hmg_v
  *   down  smoothing_steps!, local_residual!, restrict_to!(next.b, P, curr.r), fill!(next.x, 0)   (src/multigrid.jl:100-106)
  *   up    interpolate_and_sum_to!(curr.x, P, next.x), smoothing_steps!                          (src/multigrid.jl:112-115)
  * hmg_vcycle(k) == down(k); hmg_vcycle(k-1); up(k).  After `down`, x, r (the cell-local residual) and the coarse b
- * hold what the reference leaves; p and Ap are scratch (the library drops the pre-smoother's dead tail).  With
+ * hold what the reference leaves; p and Ap are scratch (the library drops the pre-smoother's dead tail).  After `up`,
+ * x and r hold what the reference leaves; p and Ap too with option "lean_post" = 0 (see above; `up` acts as the top
+ * level of a V-cycle).  With
  * option "swap_rp" each half exchanges the device pointers of the r and p handles once: call them in pairs when
  * r / p wrap caller-owned memory. */
 int hmg_vcycle_down(hmg_grid *grid, int level, int steps, hmg_vec **states);

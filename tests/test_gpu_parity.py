@@ -617,7 +617,7 @@ def test_vcycle_leaves_wrapped_buffers_consistent(oracle, ctx):
     st0 = _oracle_state(c, levels)
     results = []
     for opts in ((1, 1), (0, 0)):
-        ctx.set_option("swap_rp", opts[0]); ctx.set_option("fold_x", opts[1]); ctx.set_option("fold_prolong", opts[1]); ctx.set_option("lazy_dead", opts[1])
+        ctx.set_option("swap_rp", opts[0]); ctx.set_option("fold_x", opts[1]); ctx.set_option("fold_prolong", opts[1]); ctx.set_option("lazy_dead", opts[1]); ctx.set_option("lean_post", opts[1])
         try:
             dsts = [hmg.LevelState(c.g, i + 1) for i in range(levels)]
             top = dsts[-1]
@@ -637,10 +637,11 @@ def test_vcycle_leaves_wrapped_buffers_consistent(oracle, ctx):
             assert not np.array_equal(np.sort(raw_r, axis=0), np.sort(raw_p, axis=0))
             results.append((top.x.to_host(), r_host, p_host))
         finally:
-            ctx.set_option("swap_rp", 1); ctx.set_option("fold_x", 1); ctx.set_option("fold_prolong", 1); ctx.set_option("lazy_dead", 1)
+            ctx.set_option("swap_rp", 1); ctx.set_option("fold_x", 1); ctx.set_option("fold_prolong", 1); ctx.set_option("lazy_dead", 1); ctx.set_option("lean_post", 1)
+    # (lean_post: p and Ap are scratch after hmg_vcycle -- the reference's last p-update is dead; the plain run keeps it)
     (xa, ra, pa), (xb, rb, pb) = results
-    assert relerr(xa, xb) <= 1e-13 and relerr(ra, rb) <= 1e-12 and relerr(pa, pb) <= 1e-12
+    assert relerr(xa, xb) <= 1e-13 and relerr(ra, rb) <= 1e-12
     sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(levels)]
     sts[-1] = st0
     O.vcycle(c.impl, O.make_base_level(c.mesh, c.sig, 1.0), c.ops, sts, levels, 3)
-    assert relerr(xa, sts[-1].x) <= 1e-9 and relerr(pa, sts[-1].p) <= 1e-8 and relerr(ra, sts[-1].r) <= 1e-8
+    assert relerr(xa, sts[-1].x) <= 1e-9 and relerr(pb, sts[-1].p) <= 1e-8 and relerr(ra, sts[-1].r) <= 1e-8
