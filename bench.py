@@ -65,9 +65,14 @@ def time_to_tolerance(ctx, hmg, driver, n, refinements, tolerance):
     sigma, hist = driver.checkerboard_homogenization(n, hmg.Tet64, refinements=refinements, tolerance=tolerance, ctx=ctx,
                                                      seed=0, timings=tm)
     return {"call": f"checkerboard_homogenization({n}, Tet64, refinements={refinements}, tolerance={tolerance:g})",
-            "seconds": time.perf_counter() - t0, "setup_seconds": tm["setup_s"], "solve_seconds": tm["solve_s"],
+            "seconds": time.perf_counter() - t0, "setup_seconds": tm["setup_s"],
+            "setup_split": {"mesh_and_sigma": tm["setup_mesh_s"], "tables_and_upload": tm["setup_tables_s"],
+                            "level_vectors": tm["setup_alloc_s"], "x0_and_rhs": tm["setup_init_s"]},
+            "solve_seconds": tm["solve_s"],
             "vcycles": tm["vcycles"], "outer_steps": tm["outer_steps"], "sigma": sigma,
-            "base_mesh": f"{tm['width']}^3 unit cubes, {tm['cells']} cells"}
+            "base_mesh": f"{tm['width']}^3 unit cubes, {tm['cells']} cells",
+            "level_vector_memory": "blocks the context kept when the bench's own level vectors were destroyed (option "
+                                   "vec_pool; a fresh process allocates them in ~0.2 s, DESIGN.md section 4)"}
 
 
 def cpu_time_to_tolerance(hmg, driver, n, refinements, tolerance, max_seconds):

@@ -118,7 +118,62 @@ struct hmg_ctx {
     hipStream_t comm_stream = nullptr;       // the overlapped cut exchange runs here
     hipEvent_t ev_packed = nullptr, ev_summed = nullptr;
     int64_t comm_calls = 0, comm_doubles = 0;
+    // Level-vector memory handed back by hmg_vec_destroy, kept for the next hmg_vec_create of the same size: on this
+    // platform hipMalloc of memory the process has freed before costs ~35 ms per GB (tools/dev/alloc_probe.hip: 6 x 10 GB
+    // 0.001 s fresh, 2.05 s after a hipFree), i.e. 1.9 s of the 71 GB a second driver call allocates.
+    bool vec_pool_on = true;
+    std::vector<std::pair<size_t, void *>> vec_pool;
 };
+
+namespace {
+
+void vec_pool_trim(hmg_ctx *c)
+{
+    if (c->vec_pool.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &b : c->vec_pool) (void)hipFree(b.second);
+    c->vec_pool.clear();
+}
+
+// zero-filled device memory for one level vector (stream-ordered: kernels of the previous owner were enqueued on the
+// same stream, or joined to it by events, before the block came back)
+double *vec_alloc(hmg_ctx *c, size_t bytes)
+{
+    void *p = nullptr;
+    for (size_t i = 0; i < c->vec_pool.size(); ++i)
+        if (c->vec_pool[i].first == bytes) {
+            p = c->vec_pool[i].second;
+            c->vec_pool[i] = c->vec_pool.back();
+            c->vec_pool.pop_back();
+            break;
+        }
+    if (!p && hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        vec_pool_trim(c);                        // blocks of other sizes may be what is in the way
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+            throw std::runtime_error(std::string("hipMalloc of a level vector (") + std::to_string(bytes >> 20) +
+                                     " MiB) failed: " + hipGetErrorString(e));
+    }
+    hipError_t e = hipMemsetAsync(p, 0, bytes, c->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e));
+    }
+    return (double *)p;
+}
+
+void vec_release(hmg_ctx *c, void *p, size_t bytes)
+{
+    if (c->vec_pool_on && bytes > 0) {
+        c->vec_pool.emplace_back(bytes, p);
+        return;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(p);
+}
+
+}  // namespace
 
 namespace {
 // state of the last coarse solve, copied to pinned host memory behind the solve and read when somebody asks
@@ -187,6 +242,7 @@ struct hmg_vec {
     double *d = nullptr;
     bool own = false;
     int64_t alloc_cells = 0;
+    size_t bytes = 0;        // own: size of the allocation behind d
 };
 
 namespace {
@@ -907,6 +963,7 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
                 std::swap(r->d, p->d);                                    // p now names r_0, r the spare buffer
                 std::swap(r->own, p->own);
                 std::swap(r->alloc_cells, p->alloc_cells);
+                std::swap(r->bytes, p->bytes);
                 r_in = p->d;
             }
             if (dead) {
@@ -1380,6 +1437,7 @@ int hmg_ctx_destroy(hmg_ctx *ctx)
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
+        vec_pool_trim(ctx);
         if (ctx->comm) (void)rccl().CommDestroy(ctx->comm);
         if (ctx->ev_packed) (void)hipEventDestroy(ctx->ev_packed);
         if (ctx->ev_summed) (void)hipEventDestroy(ctx->ev_summed);
@@ -1430,6 +1488,10 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->fold_faces = value != 0;
     else if (n == "lean_post")
         ctx->lean_post = value != 0;
+    else if (n == "vec_pool") {
+        ctx->vec_pool_on = value != 0;
+        if (!ctx->vec_pool_on) vec_pool_trim(ctx);
+    }
     else if (n == "time_apply") {   // value = minimum level to time, 0 = off; resets the counters
         ctx->timer.on = value > 0;
         ctx->timer.min_level = (int)value;
@@ -1774,8 +1836,8 @@ int hmg_vec_create(hmg_grid *g, int level, hmg_vec **out)
     v->alloc_cells = g->md.ncells;
     size_t bytes = sizeof(double) * (size_t)lv.ld * (size_t)g->md.ncells;
     ensure_reduce_scratch(g->ctx, (int64_t)lv.ld * g->md.ncells);
-    HIPCHK(hipMalloc((void **)&v->d, bytes));
-    HIPCHK(hipMemsetAsync(v->d, 0, bytes, g->ctx->stream));
+    v->d = vec_alloc(g->ctx, bytes);
+    v->bytes = bytes;
     *out = v.release();
     HMG_END
 }
@@ -1799,10 +1861,7 @@ int hmg_vec_destroy(hmg_vec *v)
 {
     HMG_TRY
     if (v) {
-        if (v->own && v->d) {
-            (void)hipStreamSynchronize(v->g->ctx->stream);
-            (void)hipFree(v->d);
-        }
+        if (v->own && v->d) vec_release(v->g->ctx, v->d, v->bytes);
         delete v;
     }
     HMG_END

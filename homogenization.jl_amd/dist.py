@@ -302,7 +302,7 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
     api.broadcast_interfaces(top.x, grid, total_grids)
     api.apply_constraint(top.x, total_grids, grid)
     api.rhs_axi_grad_v(top.b, grid, xi)
-    v_prev = api.DeviceMatrix(grid, total_grids)
+    v_prev = None                                        # allocated at the first domain shrink
     rank_sum = ex.rank_sum
     cur = base
     history = []
@@ -338,6 +338,8 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
         cur = api.Mesh(cur.nodes[:nn_keep], np.ascontiguousarray(cur.elements[:ne_keep]))
         grid.shrink(ne_keep, nn_keep)
         api.apply_constraint(top.x, total_grids, grid)
+        if v_prev is None:
+            v_prev = api.DeviceMatrix(top.x.implicit, total_grids)
         v_prev.copyto(top.x)
         op.lam = lam
         api.next_rhs(top.b, top.x, grid)

@@ -212,6 +212,7 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     if sigma_grid is None:
         sigma_grid = generate_conductivity(dim, width, seed, values)
     cond = conductivity_per_element(base, sigma_grid, (total_radius + 1.0,) * dim)
+    t_mesh = time.perf_counter()
     total_grids = refinements + 1
     if save is not None:
         if not 1 <= save <= total_grids:
@@ -220,8 +221,11 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     implicit = api.ImplicitFineGrid(ctx, base, total_grids)
     op = api.L2PlusDivAGrad(implicit, lam, cond)
     ops = [op] * total_grids
+    t_grid = time.perf_counter()
     states = [api.LevelState(implicit, i + 1) for i in range(total_grids)]
     top = states[-1]
+    ctx.sync()
+    t_alloc = time.perf_counter()
     if x0 is None:
         top.x.rand(seed + 1)
     else:
@@ -229,7 +233,7 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     api.broadcast_interfaces(top.x, implicit, total_grids)
     api.apply_constraint(top.x, total_grids, implicit)
     api.rhs_axi_grad_v(top.b, implicit, xi)
-    v_prev = api.DeviceMatrix(implicit, total_grids)
+    v_prev = None                                        # allocated at the first domain shrink (10 GB at config 3)
     cur = base
     history = []
     ctx.sync()
@@ -267,17 +271,22 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
         cur = Mesh(cur.nodes[:nn_keep], np.ascontiguousarray(cur.elements[:ne_keep]))
         implicit.shrink(ne_keep, nn_keep)                # new boundary; level vectors keep their storage
         api.apply_constraint(top.x, total_grids, implicit)
+        if v_prev is None:
+            v_prev = api.DeviceMatrix(top.x.implicit, total_grids)
         v_prev.copyto(top.x)
         op.lam = lam
         api.next_rhs(top.b, top.x, implicit)
     ctx.sync()
     if timings is not None:
-        timings.update(setup_s=t_setup - t_start, solve_s=time.perf_counter() - t_setup, vcycles=len(history),
+        timings.update(setup_s=t_setup - t_start, setup_mesh_s=t_mesh - t_start, setup_tables_s=t_grid - t_mesh,
+                       setup_alloc_s=t_alloc - t_grid, setup_init_s=t_setup - t_alloc,
+                       solve_s=time.perf_counter() - t_setup, vcycles=len(history),
                        outer_steps=len({h[0] for h in history}), cells=int(base.elements.shape[0]), width=int(width))
     # the level vectors go back now, not whenever the collector gets to them (71 GB at BASELINE config 3)
     for st in states:
         st.close()
-    v_prev.close()
+    if v_prev is not None:
+        v_prev.close()
     implicit.close()
     if own_ctx:
         ctx.close()
