@@ -1423,6 +1423,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_threads = 0;
     c->L.apply_mass_only = 0;
     c->L.apply_unblocked = 0;
+    c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
     c->L.apply_pipe = 0;   // experimental (measured slower than k_apply inside the V-cycle)
     *out = c.release();
     HMG_END
@@ -1466,6 +1467,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
 
     else if (n == "apply_unblocked")
         ctx->L.apply_unblocked = value != 0;
+    else if (n == "apply_wg512")
+        ctx->L.apply_wg512 = value != 0;
     else if (n == "apply_pipe")
         ctx->L.apply_pipe = (int)value;
     else if (n == "coarse_maxit")

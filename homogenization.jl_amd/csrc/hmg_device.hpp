@@ -122,6 +122,8 @@ struct Launch {
     int apply_threads;    // 0 = auto
     int apply_mass_only;  // 1: only the mass term (next_rhs!), set around a single launch
     int apply_unblocked;  // 1: node-per-thread interior sweep instead of the register-blocked one (dev / A-B knob)
+    int apply_wg512;      // 1 (default): cells that would take the 1024-thread register-blocked instantiation take the 512-thread one:
+                          // three workgroups (three columns in flight) per CU instead of two
     int apply_pipe;       // 0 (default): k_apply; 1: plain applies of levels that qualify go through the pipelined persistent
                           // kernel (hmg_apply_pipe.hip); 2: the fused CG passes without a source vector as well
 };

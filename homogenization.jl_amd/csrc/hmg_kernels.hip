@@ -42,14 +42,15 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 #endif
 
 template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false>   // WD: instantiation for the driver integrals (flags bit 3)
-__global__ void __launch_bounds__(NT, NT >= 640 ? 8 : 1)   // 2 x 1024 / 3 x 640 threads per CU need <= 64 VGPRs
+__global__ void __launch_bounds__(NT, NT >= 640 ? 8 : RB && NT == 512 ? 6 : 1)   // 2 x 1024 threads per CU need <= 64 VGPRs, 3 x 512: 80
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
     constexpr int NDIR = DIM == 3 ? 15 : 7;
     constexpr int NTERM = DIM == 3 ? 7 : 4;
+    constexpr int WS = RB ? WSZ_RB : WSZ;
     extern __shared__ double smem[];
     double *W = smem;
-    double *xs = smem + WSZ + lv.lds_g0;
+    double *xs = smem + WS + lv.lds_g0;
     const int tid = threadIdx.x;
     const int64_t cell = a.cell_list ? (int64_t)a.cell_list[blockIdx.x] : (int64_t)blockIdx.x;
     const int nf = lv.nf;
@@ -74,7 +75,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             W[idx] = w;
         }
     }
-    for (int q = tid; q < lv.lds_g0; q += NT) smem[WSZ + q] = 0.0;
+    for (int q = tid; q < lv.lds_g0; q += NT) smem[WS + q] = 0.0;
     for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
     const double *xc = a.x + cell * lv.ld;
     double rr = 0.0, pap = 0.0;
@@ -184,7 +185,10 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the edges are dealt to the
     // waves from the last one backwards (NE per wave: 1 of 16 waves, 2 of 4), the last wave takes the corners instead
     // of an interior block -- the 945 blocks of level 6 fill waves 0..14, the 152 of level 5 waves 0..2.
-    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, FI = 2, NE = NW >= 6 ? 1 : 2;
+    // 512-thread instantiation (three workgroups per CU): 2 waves per face with 4 runs each, the interior blocks in two passes
+    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, NE = NW >= 6 ? 1 : 2;
+    constexpr int FI = RB && NT == 512 ? 4 : 2;
+    constexpr int NPASS = RB && NT == 512 ? 2 : 1;
     const int wave = tid >> 6, lane = tid & 63;
     const int face = wave / WPF, ft0 = (wave % WPF) * (FI * 64);
     int edge[NE], ebase[NE];
@@ -194,7 +198,9 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         if (edge[q] >= lv.nedge) edge[q] = -1;
         ebase[q] = lv.off_edge + (edge[q] < 0 ? 0 : edge[q]) * lv.nei;
     }
-    uint32_t fw[FI] = {0u, 0u}, ew[NE][1], cw = 0u;
+    uint32_t fw[FI], ew[NE][1], cw = 0u;
+#pragma unroll
+    for (int q = 0; q < FI; ++q) fw[q] = 0u;
     uint32_t p0 = 0u, p1 = 0u;
     double wv = 0.0;                 // RB: lane d: interior weight d; lane 16 + d: this wave's face; lane 32 + 16 q + d: its edge q
     if (RB) {
@@ -225,11 +231,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
 #pragma unroll
         for (int t = 0; t < NTERM; ++t) wv += c7[t] * sc7[t];
         if (wave == NW - 1) {        // the corners' rows: per-lane weights, private to this wave (LDS ops of a wave are in order)
-            for (int idx = (1 + lv.nface + lv.nedge) * NDIR + lane; idx < lv.ncls * NDIR; idx += 64) {
+            const int cbase = (1 + lv.nface + lv.nedge) * NDIR;        // (the only rows in LDS: stored from W[0] on)
+            for (int idx = cbase + lane; idx < lv.ncls * NDIR; idx += 64) {
                 double w = 0.0;
 #pragma unroll
                 for (int t = 0; t < NTERM; ++t) w += lv.ctab[(size_t)idx * NTERM + t] * sc7[t];
-                W[idx] = w;
+                W[idx - cbase] = w;
             }
         }
     } else {
@@ -240,9 +247,9 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const uint32_t *iw = RB ? lv.blk_word : lv.sweep32;
     const uint16_t *is = RB ? lv.blk_slot : lv.sweep_slot;
     uint32_t q0 = iw[tid];
-    uint32_t q1 = RB ? 0u : iw[tid + NT];
+    uint32_t q1 = RB && NPASS < 2 ? 0u : iw[tid + NT];
     int s0 = (int)is[tid];
-    int s1 = RB ? 0 : (int)is[tid + NT];
+    int s1 = RB && NPASS < 2 ? 0 : (int)is[tid + NT];
     uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
     if (FUSED) {
         const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
@@ -255,12 +262,13 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     HMG_STAMP(3);
 
     // surface entities
+    const int wbase = RB ? (1 + lv.nface + lv.nedge) * NDIR : 0;     // RB: the LDS table starts at the corners' rows
     auto surface_node = [&](int t, uint32_t pw) {      // any class: weight row read from the LDS class table tap by tap
         const double sv = sc ? sc[t] : 0.0;
         int L, len, A, B, cls;
         decode32<DIM>(pw, m, L, len, A, B, cls);
         double ctr;
-        double o = stencil_eval_c<DIM>(W + cls * NDIR, xs, L, len, A, B, ctr);
+        double o = stencil_eval_c<DIM>(W + cls * NDIR - wbase, xs, L, len, A, B, ctr);
         if (!wdot) o = sv + o;
         if ((dm >> (cls - 1)) & 1u) o = 0.0;
         if (!FUSED || oc) oc[t] = o;
@@ -274,10 +282,14 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     if (RB) {
         if (DIM == 3) {
             const bool fdir = (dm >> face) & 1u;
-            const double fmult = (double)((mq[0] >> (8 * face)) & 0xffu);
+            const double fmult = (double)((mq[0] >> (8 * (face & 3))) & 0xffu);
             const int fbase = lv.off_face + face * lv.nfi;
-            const double nopre[FI] = {0.0, 0.0};
-            if (face == 0)
+            double nopre[FI];
+#pragma unroll
+            for (int q = 0; q < FI; ++q) nopre[q] = 0.0;
+            if (face >= 4)
+                ;
+            else if (face == 0)
                 face_items<0, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
             else if (face == 1)
                 face_items<1, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
@@ -327,6 +339,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap, wdot);
             else
                 interior_block<RB ? RB : 1, FUSED, false>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap);
+        }
+        if (DIM == 3 && NPASS > 1 && tid + NT < nsw) {      // second pass (the host selects NT >= nblk / 2)
+            if (sc)
+                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q1, s1, sc, oc, pap, wdot);
+            else
+                interior_block<RB ? RB : 1, FUSED, false>(w0, xs, m, nf >> 1, q1, s1, sc, oc, pap);
         }
     } else {
         const int nit_sweep = (nsw + NT - 1) / NT;
@@ -594,6 +612,11 @@ size_t apply_lds_bytes(const LevelDev &lv)
     return sizeof(double) * (size_t)(WSZ + lv.lds_g0 + lv.nf + lv.lds_g1);
 }
 
+static size_t apply_lds_bytes_rb(const LevelDev &lv)   // register-blocked instantiations: only the corners' weight rows in LDS
+{
+    return sizeof(double) * (size_t)(WSZ_RB + lv.lds_g0 + lv.nf + lv.lds_g1);
+}
+
 template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
@@ -638,7 +661,7 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     else if (nt <= 256 && nf <= 1024) {
         if (DIM == 3 && lv.blk_R == 4 && lv.nblk <= 192 && lv.nfi <= 128 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 &&
             !L.apply_unblocked)
-            launch_apply_generic<DIM, 256, 4, FUSED, DIM == 3 ? 4 : 0, WD>(L, lv, mesh, a, lds);
+            launch_apply_generic<DIM, 256, 4, FUSED, DIM == 3 ? 4 : 0, WD>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
         else
             launch_apply_generic<DIM, 256, 4, FUSED, 0, WD>(L, lv, mesh, a, lds);
     }
@@ -646,13 +669,24 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         launch_apply_generic<DIM, 256, 8, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 640) {
         if constexpr (!WD) {
-            if (nt <= 512)
-                launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
-            else
+            if (nt <= 512) {
+                if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 1024 && lv.nfi <= 512 && lv.nei <= 64 && lv.nedge == 6 &&
+                    lv.ncorner == 4 && !L.apply_unblocked)
+                    launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                else
+                    launch_apply_generic<DIM, 512, 13, FUSED>(L, lv, mesh, a, lds);
+            } else
                 launch_apply_generic<DIM, 640, 11, FUSED>(L, lv, mesh, a, lds);
         }
-    } else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked)
-        launch_apply_generic<DIM, 1024, 7, FUSED, DIM == 3 ? 6 : 0, WD>(L, lv, mesh, a, lds);
+    } else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked) {
+        if constexpr (!WD) {
+            if (L.apply_wg512 && lv.nfi <= 512) {
+                launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                return;
+            }
+        }
+        launch_apply_generic<DIM, 1024, 7, FUSED, DIM == 3 ? 6 : 0, WD>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+    }
     else
         launch_apply_generic<DIM, 1024, 7, FUSED, 0, WD>(L, lv, mesh, a, lds);
 }

@@ -20,6 +20,8 @@ namespace hmg {
 static inline void check_launch() { HMG_HIP_CHECK(hipGetLastError()); }
 
 constexpr int WSZ = 232;   // LDS doubles reserved for the class weight table (>= 15*15, 16-B multiple)
+constexpr int WSZ_RB = 64; // ... of the register-blocked instantiations: only the corners' rows (4 x 15) live in LDS.  With it a
+                           // level-6 cell takes 53 192 B: three workgroups per CU (3 x 53 248 <= 160 KB)
 
 // ---------------------------------------------------------------------------------------------
 // reductions

@@ -42,7 +42,9 @@ int hmg_ctx_create(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_create_on_stream(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_destroy(hmg_ctx *ctx);
 int hmg_ctx_sync(hmg_ctx *ctx);
-/* option names: "apply_threads" (workgroup size of the apply kernel, 0 = auto), "fuse_cg" (1 = fused CG pass,
+/* option names: "apply_threads" (workgroup size of the apply kernel, 0 = auto), "apply_wg512" (1 = default: level-6
+ * cells -- 6545 nodes, 52 KB of LDS -- are applied by 512-thread workgroups, three resident per CU; 0 = by 1024-thread
+ * workgroups, two per CU; same arithmetic per node), "fuse_cg" (1 = fused CG pass,
  * default; read when a grid is created), "fold_x" / "lazy_dead" / "swap_rp" / "fold_prolong" (1 = default: hmg_vcycle
  * folds the pre-smoother's last x-update into the local residual / lets the pre-smoother's last step write nothing
  * and folds both pending x-updates / lets CG step 0 take r itself as p by exchanging the two handles' device

@@ -58,6 +58,42 @@ def test_l6_apply_every_workgroup_size(case6, ctx, threads):
         ctx.set_option("apply_threads", 0)
 
 
+@pytest.mark.parametrize("wg", [0, 1])
+def test_l6_workgroup_shapes(case6, ctx, wg):
+    """Option apply_wg512: 0 = k_apply<3,1024,7,*,6> (two workgroups per CU), 1 = k_apply<3,512,13,*,6> (two waves per face
+    with four runs each, the interior blocks in two passes, corner rows only in LDS: three workgroups -- three columns in
+    flight -- per CU).  Residual with a source vector, the fused CG smoother (full
+    state) and a V-cycle through all six levels."""
+    c = case6
+    O, lev = c.O, 6
+    ctx.set_option("apply_wg512", wg)
+    try:
+        st = O.LevelState.create(c.mesh.nelements(), c.impl.nf(lev))
+        st.x[...] = c.rand(lev); st.b[...] = c.rand(lev)
+        O.local_residual(c.impl, c.ops[lev - 1], st, lev)
+        dst = hmg.LevelState(c.g, lev)
+        dst.x.from_host(st.x); dst.b.from_host(st.b)
+        hmg.local_residual(c.g, c.A, dst, lev)
+        assert relerr(dst.r.to_host(), st.r) <= TOL
+        st = _oracle_state(c, lev)
+        dst = hmg.LevelState(c.g, lev)
+        dst.x.from_host(st.x); dst.b.from_host(st.b)
+        O.smoothing_steps(3, c.impl, c.ops[lev - 1], st, lev)
+        hmg.smoothing_steps(3, c.g, c.A, dst, lev)
+        for name in ("x", "r", "p", "Ap"):
+            assert relerr(getattr(dst, name).to_host(), getattr(st, name)) <= 1e-10, name
+        sts = [O.LevelState.create(c.mesh.nelements(), c.impl.nf(i + 1)) for i in range(lev)]
+        sts[-1] = _oracle_state(c, lev)
+        dsts = [hmg.LevelState(c.g, i + 1) for i in range(lev)]
+        dsts[-1].x.from_host(sts[-1].x); dsts[-1].b.from_host(sts[-1].b)
+        O.vcycle(c.impl, O.make_base_level(c.mesh, c.sig, c.lam), c.ops, sts, lev, 3)
+        hmg.vcycle(c.g, hmg.BaseLevel(c.g), [c.A] * lev, dsts, lev, 3)
+        assert relerr(dsts[-1].x.to_host(), sts[-1].x) <= 1e-9
+        assert relerr(dsts[-1].r.to_host(), sts[-1].r) <= 1e-8
+    finally:
+        ctx.set_option("apply_wg512", DEFAULT_WG512)
+
+
 @pytest.mark.parametrize("pipe", [1, 2])
 def test_l6_pipelined_kernel(case6, ctx, pipe):
     """Option apply_pipe: the persistent software-pipelined form of the same apply (hmg_apply_pipe.hip: one workgroup per
@@ -148,6 +184,7 @@ def test_l6_smoothing_steps(case6, steps):
     assert relerr(dst.Ap.to_host(), st.Ap) <= 1e-10
 
 
+DEFAULT_WG512 = 1      # hmg_ctx_create's default (see hmg_ctx_set_option in include/hmg.h)
 OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead", "lean_post")
 
 
