@@ -103,6 +103,7 @@ struct hmg_ctx {
     bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
+    bool prolong_gather = true;  // folded prolongation, level 6: parents gathered from global memory instead of an LDS copy of the coarse column
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -908,6 +909,8 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             a.xcoarse = xcoarse->d;
             a.ldc = lev(g, level - 1).ld;
             a.xout = x->d;
+            // (cells that fill a third of the LDS: no room for the coarse column next to three resident images)
+            if (g->ctx->prolong_gather && apply_lds_bytes(lv) > 48 * 1024) a.flags |= 64;
             apply_then_sum(g, lv, a, true, -1, -1);
         } else {
             apply_then_sum(g, lv, a, false, -1, -1);
@@ -1491,6 +1494,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->fold_faces = value != 0;
     else if (n == "lean_post")
         ctx->lean_post = value != 0;
+    else if (n == "prolong_gather")
+        ctx->prolong_gather = value != 0;
     else if (n == "vec_pool") {
         ctx->vec_pool_on = value != 0;
         if (!ctx->vec_pool_on) vec_pool_trim(ctx);

@@ -96,14 +96,23 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // src/interpolation.jl:64-74: identity rows += 1.0 c[a], midpoints += 0.5 c[a], += 0.5 c[b] in the CSC
         // column order), from the cell's coarse column staged in LDS behind the lattice image
         const double *ccol = FUSED && a.xcoarse ? a.xcoarse + cell * a.ldc : nullptr;
+        // (flags bit 6: the coarse column is not staged -- every slot gathers its one or two parents from global memory,
+        //  L1/L2 hits after the first touch of the 7.6 KB column; the LDS then holds nothing but the image, so that the
+        //  512-thread instantiation keeps three workgroups per CU)
+        const bool cgather = FUSED && (a.flags & 64);
         double *cs = xs + nf + lv.lds_g1;
         double cval = 0.0;
-        if (ccol) {
+        if (ccol && !cgather) {
             if (tid < lv.nf_coarse) cval = ccol[tid];
             for (int q = tid + NT; q < lv.nf_coarse; q += NT) cs[q] = ccol[q];
         }
         auto prolong = [&](double v, uint32_t w) {
             const uint32_t pa = w & 0xffffu, pb = w >> 16;
+            if (cgather) {
+                if (pa == pb) return v + ccol[pa];
+                v += 0.5 * ccol[pa];
+                return v + 0.5 * ccol[pb];
+            }
             if (pa == pb) return v + cs[pa];
             v += 0.5 * cs[pa];
             return v + 0.5 * cs[pb];
@@ -125,7 +134,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     if (FUSED) pw[q] = ccol ? lv.par32[t] : 0u;
                 }
             }
-            if (FUSED && q0 == 0 && ccol) {   // coarse column complete before the first use
+            if (FUSED && q0 == 0 && ccol && !cgather) {   // coarse column complete before the first use
                 if (tid < lv.nf_coarse) cs[tid] = cval;
                 __syncthreads();
             }
@@ -621,7 +630,7 @@ template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
     auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD>;
-    if (FUSED && a.xcoarse) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
+    if (FUSED && a.xcoarse && !(a.flags & 64)) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;

@@ -53,7 +53,9 @@ int hmg_ctx_sync(hmg_ctx *ctx);
  * p-update and, below the top level, everything of the last CG step but x += alpha p; x of every level and r of the
  * top level are unchanged bit for bit, p / Ap (and r below the top level) are scratch on return, as they are for the
  * reference's own callers: the next smoothing_steps! overwrites them before reading, src/multigrid.jl:46-50;
- * 0 = they hold what the reference leaves), "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
+ * 0 = they hold what the reference leaves), "prolong_gather" (1 = default: on level 6 the folded prolongation gathers
+ * the parents from global memory instead of staging the coarse column in LDS, which would cost the third resident
+ * workgroup), "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
  * hmg_vec_create of the same size -- re-allocating freed device memory costs ~35 ms per GB here; 0 = free at once and
  * release what is held; hmg_ctx_destroy releases it too), "coarse_maxit", "coarse_check",
  * "time_apply"; "coarse_rtol" via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab

@@ -185,7 +185,7 @@ def test_l6_smoothing_steps(case6, steps):
 
 
 DEFAULT_WG512 = 1      # hmg_ctx_create's default (see hmg_ctx_set_option in include/hmg.h)
-OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead", "lean_post")
+OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead", "lean_post", "prolong_gather")
 
 
 @pytest.mark.parametrize("plain", [0, 1])
@@ -220,10 +220,11 @@ def test_l6_vcycle_down_leg(case6, ctx, steps, plain):
             ctx.set_option(o, 1)
 
 
-@pytest.mark.parametrize("plain", [0, 1])
+@pytest.mark.parametrize("plain", [0, 1, 2])
 def test_l6_vcycle_up_leg(case6, ctx, plain):
     """Second half: interpolate_and_sum_to!(curr.x, P, next.x), smoothing_steps! (src/multigrid.jl:112-115).  plain = 0:
-    the prolongation rides in the load phase of the post-smoother's first residual (coarse column staged in LDS)."""
+    the prolongation rides in the load phase of the post-smoother's first residual (parents gathered from global memory;
+    plain = 2: coarse column staged in LDS)."""
     c = case6
     O, lev, steps = c.O, 6, 3
     st = _oracle_state(c, lev)
@@ -234,7 +235,9 @@ def test_l6_vcycle_up_leg(case6, ctx, plain):
     O.interpolate_and_sum_to(st.x, c.impl.reference.interops[lev - 2], xc)
     O.smoothing_steps(steps, c.impl, c.ops[lev - 1], st, lev)
     for o in OPTS:
-        ctx.set_option(o, 0 if plain else 1)
+        ctx.set_option(o, 0 if plain == 1 else 1)
+    if plain == 2:                                  # every fold, the coarse column staged in LDS (two workgroups per CU)
+        ctx.set_option("prolong_gather", 0)
     try:
         states = [None] * 6
         states[4], states[5] = hmg.LevelState(c.g, 5), hmg.LevelState(c.g, 6)
@@ -247,7 +250,7 @@ def test_l6_vcycle_up_leg(case6, ctx, plain):
         #  are what hmg_vcycle runs; the handles still name r and p)
         # lean_post (what hmg_vcycle runs on its finest level): x and r as the reference leaves them, the last
         # p-update is dead and skipped, the last Ap keeps its face sums in the r-update; plain keeps the full state
-        if plain:
+        if plain == 1:
             assert relerr(states[5].p.to_host(), st.p) <= 1e-10
             assert relerr(states[5].Ap.to_host(), st.Ap) <= 1e-10
     finally:
