@@ -94,7 +94,11 @@ struct ApplyTimer {
     int64_t launches = 0;
 };
 
+// Lifetimes: a vector keeps its grid alive, a grid its context (reference counts, single host thread): hmg_*_destroy
+// hands the caller's reference back, the object goes when the last dependant has gone -- the order in which a host
+// (finalizers of a garbage-collected language in particular) destroys handles does not matter.
 struct hmg_ctx {
+    int refs = 1;
     ApplyTimer timer;
     bool fuse_cg_default = true;
     bool fold_x = true;   // V-cycle: pre-smoother's last x-update rides with the local residual
@@ -188,6 +192,7 @@ struct CoarseProbe {
 }  // namespace
 
 struct hmg_grid {
+    int refs = 1;
     hmg_ctx *ctx = nullptr;
     int dim = 0, nlevels = 0;
     std::vector<LevelTables> lt;
@@ -1381,6 +1386,38 @@ int comm_exchange_end(void *user)
 }  // namespace
 
 // =============================================================================================
+static void ctx_unref(hmg_ctx *ctx)
+{
+    if (!ctx || --ctx->refs > 0) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->timer.pool) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    vec_pool_trim(ctx);
+    if (ctx->comm) (void)rccl().CommDestroy(ctx->comm);
+    if (ctx->ev_packed) (void)hipEventDestroy(ctx->ev_packed);
+    if (ctx->ev_summed) (void)hipEventDestroy(ctx->ev_summed);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+static void grid_unref(hmg_grid *grid)
+{
+    if (!grid || --grid->refs > 0) return;
+    hmg_ctx *c = grid->ctx;
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+    }
+    if (grid->probe && grid->probe->h) (void)hipHostFree(grid->probe->h);
+    if (grid->probe && grid->probe->ev) (void)hipEventDestroy(grid->probe->ev);
+    delete grid;
+    ctx_unref(c);
+}
+
 static double read_scalar(hmg_ctx *c, int slot);
 
 extern "C" {
@@ -1435,20 +1472,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
 int hmg_ctx_destroy(hmg_ctx *ctx)
 {
     HMG_TRY
-    if (ctx) {
-        (void)hipStreamSynchronize(ctx->stream);
-        for (auto &ev : ctx->timer.pool) {
-            (void)hipEventDestroy(ev.first);
-            (void)hipEventDestroy(ev.second);
-        }
-        vec_pool_trim(ctx);
-        if (ctx->comm) (void)rccl().CommDestroy(ctx->comm);
-        if (ctx->ev_packed) (void)hipEventDestroy(ctx->ev_packed);
-        if (ctx->ev_summed) (void)hipEventDestroy(ctx->ev_summed);
-        if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
-        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-    }
+    ctx_unref(ctx);
     HMG_END
 }
 
@@ -1571,6 +1595,7 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
     build_mesh_tables(dim, nnodes, coords, ncells, cells, g->mesh_full);
     upload_levels(g.get());
     upload_mesh(g.get());
+    if (ctx) ctx->refs += 1;
     *out = g.release();
     HMG_END
 }
@@ -1616,6 +1641,7 @@ int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes
     upload_levels(g.get());
     upload_mesh(g.get());
     finish_partition(g.get());
+    if (ctx) ctx->refs += 1;
     *out = g.release();
     HMG_END
 }
@@ -1623,12 +1649,7 @@ int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes
 int hmg_grid_destroy(hmg_grid *grid)
 {
     HMG_TRY
-    if (grid) {
-        if (grid->ctx) (void)hipStreamSynchronize(grid->ctx->stream);
-        if (grid->probe && grid->probe->h) (void)hipHostFree(grid->probe->h);
-        if (grid->probe && grid->probe->ev) (void)hipEventDestroy(grid->probe->ev);
-        delete grid;
-    }
+    grid_unref(grid);
     HMG_END
 }
 
@@ -1846,6 +1867,7 @@ int hmg_vec_create(hmg_grid *g, int level, hmg_vec **out)
     ensure_reduce_scratch(g->ctx, (int64_t)lv.ld * g->md.ncells);
     v->d = vec_alloc(g->ctx, bytes);
     v->bytes = bytes;
+    g->refs += 1;
     *out = v.release();
     HMG_END
 }
@@ -1861,6 +1883,7 @@ int hmg_vec_wrap(hmg_grid *g, int level, void *device_ptr, hmg_vec **out)
     v->own = false;
     v->alloc_cells = g->md.ncells;
     v->d = (double *)device_ptr;
+    g->refs += 1;
     *out = v.release();
     HMG_END
 }
@@ -1870,7 +1893,9 @@ int hmg_vec_destroy(hmg_vec *v)
     HMG_TRY
     if (v) {
         if (v->own && v->d) vec_release(v->g->ctx, v->d, v->bytes);
+        hmg_grid *g = v->g;
         delete v;
+        grid_unref(g);
     }
     HMG_END
 }

@@ -10,7 +10,9 @@
  * Conventions
  *   - every function returns 0 on success, non-zero on failure; hmg_last_error() gives the message
  *     (thread-local).  No exception or longjmp crosses the boundary.
- *   - handles are opaque, created and destroyed by the library.
+ *   - handles are opaque, created and destroyed by the library.  A vector keeps its grid alive and a grid its context
+ *     (reference counts): the hmg_*_destroy calls may come in any order -- e.g. from the finalizers of a garbage-
+ *     collected host -- and device memory goes back when the last dependant has been destroyed.
  *   - host arrays use the reference's API layout: level vectors are Nf x Ne column-major FP64 in
  *     the reference's hierarchical node order (src/multilevel_reference.jl:41-61); meshes use
  *     1-based node ids with every cell's tuple ascending (src/implicit_fine_grid.jl:14).
