@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 #define HMG_STAMP(i)
 #endif
 
-template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false>   // WD: instantiation for the driver integrals (flags bit 3)
+// WD: instantiation for the driver integrals (flags bit 3); CG: the folded prolongation gathers from global memory (flags bit 6)
+template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false, bool CG = false>
 __global__ void __launch_bounds__(NT, NT >= 640 ? 8 : RB && NT == 512 ? 6 : 1)   // 2 x 1024 threads per CU need <= 64 VGPRs, 3 x 512: 80
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
@@ -96,10 +97,10 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // src/interpolation.jl:64-74: identity rows += 1.0 c[a], midpoints += 0.5 c[a], += 0.5 c[b] in the CSC
         // column order), from the cell's coarse column staged in LDS behind the lattice image
         const double *ccol = FUSED && a.xcoarse ? a.xcoarse + cell * a.ldc : nullptr;
-        // (flags bit 6: the coarse column is not staged -- every slot gathers its one or two parents from global memory,
+        // (CG, flags bit 6: the coarse column is not staged -- every slot gathers its one or two parents from global memory,
         //  L1/L2 hits after the first touch of the 7.6 KB column; the LDS then holds nothing but the image, so that the
         //  512-thread instantiation keeps three workgroups per CU)
-        const bool cgather = FUSED && (a.flags & 64);
+        constexpr bool cgather = FUSED && CG;
         double *cs = xs + nf + lv.lds_g1;
         double cval = 0.0;
         if (ccol && !cgather) {
@@ -626,11 +627,11 @@ static size_t apply_lds_bytes_rb(const LevelDev &lv)   // register-blocked insta
     return sizeof(double) * (size_t)(WSZ_RB + lv.lds_g0 + lv.nf + lv.lds_g1);
 }
 
-template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false>
+template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false, bool CG = false>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
-    auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD>;
-    if (FUSED && a.xcoarse && !(a.flags & 64)) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
+    auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD, CG>;
+    if (FUSED && a.xcoarse && !CG) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
@@ -690,7 +691,11 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     } else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked) {
         if constexpr (!WD) {
             if (L.apply_wg512 && lv.nfi <= 512) {
-                launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                if (FUSED && DIM == 3 && a.xcoarse && (a.flags & 64))   // (own instantiation: the gather costs the others registers)
+                    launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0, false, FUSED && DIM == 3>(L, lv, mesh, a,
+                                                                                                      apply_lds_bytes_rb(lv));
+                else
+                    launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
                 return;
             }
         }

@@ -16,6 +16,7 @@ ap.add_argument("--width", type=int, default=32)
 ap.add_argument("--levels", type=int, default=6)
 ap.add_argument("--pipe", type=int, default=0, help="1/2: the pipelined persistent kernel (stamps: iteration start, loads issued, cell evaluated, next image written, barrier passed)")
 ap.add_argument("--wg512", type=int, default=1, help="option apply_wg512: 1 = three 512-thread workgroups per CU, 0 = two of 1024 threads")
+ap.add_argument("--nres", type=int, default=0, help="resident workgroups on the chip (0: 768 / 512 by --wg512; level 5: 2048)")
 ap.add_argument("--mode", default="ap", help="ap | res | cg0 (fused CG step 0: p = r stored, 24 B/DOF) | cg1 (fused CG step 1, 48 B/DOF)")
 a = ap.parse_args()
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhmg_hip_phase_timing.so")
@@ -62,7 +63,7 @@ life = (st[:, 6] - st[:, 0]) * tick / 1e3
 print(f"  {'workgroup lifetime (stamped)':32s} mean {life.mean():7.2f} us")
 # slot turnaround: sort by start time; with 512 resident workgroups, start[i + 512] - end-ish
 s0 = np.sort(st[:, 0]); e5 = np.sort(st[:, 6])
-nres = 768 if a.wg512 else 512
+nres = a.nres or (768 if a.wg512 else 512)
 gap = (s0[nres:] - e5[:-nres]) * tick / 1e3
 print(f"  start of workgroup i+{nres} minus end of i (sorted): mean {gap.mean():7.2f} us  (launch + drain overhead per slot)")
 print(f"  per-slot period: {(s0[-1] - s0[0]) * tick / 1e3 / (len(s0) / nres):.2f} us")
