@@ -31,7 +31,7 @@ def counters(pattern):
         return acc
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if "k_apply<3, 1024" in n:
+        if "k_apply<3, 1024, 7" in n or "k_apply<3, 512, 13" in n:       # the finest level of config 3 (either workgroup shape)
             acc["k_apply_L6_fused" if "true" in n else "k_apply_L6_plain"][r["Counter_Name"]].append(float(r["Counter_Value"]))
         elif "k_cg_rupdate" in n:
             acc["k_cg_rupdate"][r["Counter_Name"]].append(float(r["Counter_Value"]))
