@@ -121,6 +121,13 @@ def main():
     ap.add_argument("--apply-threads", type=int, default=None)
     args = ap.parse_args()
 
+    # Only the JSON line goes to this process's stdout: libraries underneath write there too (RCCL prints a version
+    # banner when a communicator is created, gloo its rank-connection lines), so file descriptor 1 points at stderr until
+    # the line is printed.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import homogenization_jl_amd as hmg
@@ -270,7 +277,10 @@ def main():
             if not args.no_cpu_baseline:
                 ttt["config2_cpu"] = cpu_time_to_tolerance(hmg, driver, 1, 4, 1e-5, args.cpu_driver_seconds)
             out["time_to_tolerance"] = ttt
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 
