@@ -645,3 +645,29 @@ def test_vcycle_leaves_wrapped_buffers_consistent(oracle, ctx):
     sts[-1] = st0
     O.vcycle(c.impl, O.make_base_level(c.mesh, c.sig, 1.0), c.ops, sts, levels, 3)
     assert relerr(xa, sts[-1].x) <= 1e-9 and relerr(pb, sts[-1].p) <= 1e-8 and relerr(ra, sts[-1].r) <= 1e-8
+
+
+def test_handles_may_be_destroyed_in_any_order(oracle):
+    """include/hmg.h: a vector keeps its grid alive, a grid its context.  Destroying the context, then the grid, then the
+    vectors (what the finalizers of a garbage-collected host may do) leaves the vectors usable and frees everything
+    with the last one; a destroyed vector's block is handed to the next vector of the same size (option vec_pool),
+    zero-filled again."""
+    O = oracle
+    m = O.order_nodes_and_elements_by_magnitude(O.hypercube(3, 2, origin=(-1.0, -1.0, -1.0)))
+    ctx = hmg.Context(0)
+    g = hmg.ImplicitFineGrid(ctx, m, 3)
+    a = hmg.DeviceMatrix(g, 3).fill(2.0)
+    b = hmg.DeviceMatrix(g, 3).fill(3.0)
+    ptr_b = b.device_ptr()
+    b.close()
+    c = hmg.DeviceMatrix(g, 3)
+    assert c.device_ptr() == ptr_b and not c.to_host().any()
+    c.fill(3.0)
+    n = a.shape[0] * a.shape[1]
+    ctx.close()                                   # the caller's reference only
+    assert g.ncells() == m.nelements()            # the grid still answers
+    g.close()                                     # hmg_grid_destroy while two of its vectors live
+    assert hmg.dot(a, c) == 6.0 * n
+    a.close()
+    assert hmg.dot(c, c) == 9.0 * n
+    c.close()                                     # last reference: grid and context go now
