@@ -655,7 +655,7 @@ def test_handles_may_be_destroyed_in_any_order(oracle):
     O = oracle
     m = O.order_nodes_and_elements_by_magnitude(O.hypercube(3, 2, origin=(-1.0, -1.0, -1.0)))
     ctx = hmg.Context(0)
-    g = hmg.ImplicitFineGrid(ctx, m, 3)
+    g = hmg.ImplicitFineGrid(ctx, hmg.Mesh(m.nodes, m.elements + 1), 3)
     a = hmg.DeviceMatrix(g, 3).fill(2.0)
     b = hmg.DeviceMatrix(g, 3).fill(3.0)
     ptr_b = b.device_ptr()
