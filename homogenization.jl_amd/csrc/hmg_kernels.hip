@@ -78,6 +78,108 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     }
     for (int q = tid; q < lv.lds_g0; q += NT) smem[WS + q] = 0.0;
     for (int q = tid; q < lv.lds_g1; q += NT) xs[nf + q] = 0.0;
+    // Roles and table words.  (pos32 / sweep32 / sweep_slot / blk_* carry TABLE_PAD entries of padding -- zero words, slot
+    // 0xffff -- so the two-ahead prefetch needs no bounds checks and both loops have a wave-uniform trip count.)
+    // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the edges are dealt to the
+    // waves from the last one backwards (NE per wave: 1 of 16 waves, 2 of 4), the last wave takes the corners instead
+    // of an interior block -- the 945 blocks of level 6 fill waves 0..14, the 152 of level 5 waves 0..2.
+    // 512-thread instantiation (three workgroups per CU): 2 waves per face with 4 runs each, the interior blocks in two passes
+    const int m = lv.m;
+    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, NE = NW >= 6 ? 1 : 2;
+    constexpr int FI = RB && NT == 512 ? 4 : 2;
+    constexpr int NPASS = RB && NT == 512 ? 2 : 1;
+    // EARLY (register-blocked instantiations with registers to spare, <= 512 threads): the class rows and the
+    // multiplicities are requested BEFORE the column loads and combined while the first batch of them is in flight
+    // (vmcnt counts in order: waiting for the rows does not wait for the column) -- two registers live across the load
+    // phase -- instead of in an exposed chain of L2 round trips between the load phase and the barrier.  (Fetching the
+    // addressing words early as well costs the fused instantiation 60 spilled VGPRs.)
+    constexpr bool EARLY = RB && NT <= 256;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int face = wave / WPF, ft0 = (wave % WPF) * (FI * 64);
+    int edge[NE], ebase[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        edge[q] = NW - 1 - wave + q * NW;
+        if (edge[q] >= lv.nedge) edge[q] = -1;
+        ebase[q] = lv.off_edge + (edge[q] < 0 ? 0 : edge[q]) * lv.nei;
+    }
+    uint32_t fw[FI], ew[NE][1], cw = 0u;
+#pragma unroll
+    for (int q = 0; q < FI; ++q) fw[q] = 0u;
+    uint32_t p0 = 0u, p1 = 0u;
+    double wv = 0.0;                 // RB: lane d: interior weight d; lane 16 + d: this wave's face; lane 32 + 16 q + d: its edge q
+    double c7[NTERM];
+    uint32_t q0 = 0u, q1 = 0u;
+    int s0 = 0, s1 = 0;
+    uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
+    uint32_t mqr[4] = {0, 0, 0, 0};
+    uint32_t dm = 0u;
+    const uint32_t *iw = RB ? lv.blk_word : lv.sweep32;
+    const uint16_t *is = RB ? lv.blk_slot : lv.sweep_slot;
+    auto issue_rows = [&]() {           // class rows (L2-resident table) x the cell's 7 scales, multiplicities, Dirichlet mask
+        dm = (a.flags & 1) ? dmask[cell] : 0u;
+        if (RB) {
+            int row = 0;
+            if (lane < 15)
+                row = lane;
+            else if (lane >= 16 && lane < 31)
+                row = (1 + face) * NDIR + lane - 16;
+            else if (lane >= 32 && lane < 47 && edge[0] >= 0)
+                row = (1 + lv.nface + edge[0]) * NDIR + lane - 32;
+            else if (NE > 1 && lane >= 48 && lane < 63 && edge[NE - 1] >= 0)
+                row = (1 + lv.nface + edge[NE - 1]) * NDIR + lane - 48;
+#pragma unroll
+            for (int t = 0; t < NTERM; ++t) c7[t] = lv.ctab[(size_t)row * NTERM + t];
+        }
+        if (FUSED && a.mult) {
+            const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mqr[q] = mp[q];
+        }
+    };
+    auto issue_words = [&]() {          // addressing words of this thread's surface runs and interior blocks
+        if (RB) {
+#pragma unroll
+            for (int q = 0; q < FI; ++q) {
+                const int ti = ft0 + q * 64 + lane;
+                if (ti < lv.nfi) fw[q] = lv.pos32[lv.off_face + face * lv.nfi + ti];
+            }
+#pragma unroll
+            for (int q = 0; q < NE; ++q) ew[q][0] = edge[q] >= 0 && lane < lv.nei ? lv.pos32[ebase[q] + lane] : 0u;
+            if (wave == NW - 1 && lane < lv.ncorner) cw = lv.pos32[lane];
+        } else {
+            p0 = lv.pos32[tid];
+            p1 = lv.pos32[tid + NT];
+        }
+        q0 = iw[tid];
+        q1 = RB && NPASS < 2 ? 0u : iw[tid + NT];
+        s0 = (int)is[tid];
+        s1 = RB && NPASS < 2 ? 0 : (int)is[tid + NT];
+    };
+    auto finish_tables = [&]() {
+        if (RB) {
+            double sc7[NTERM];
+#pragma unroll
+            for (int t = 0; t < NTERM - 1; ++t) sc7[t] = (a.flags & 2) ? 0.0 : a.alpha * readlane_f64(cv, t);
+            sc7[NTERM - 1] = a.alpha * a.lambda * ((a.flags & 16) ? 1.0 : readlane_f64(cv, NTERM - 1));
+#pragma unroll
+            for (int t = 0; t < NTERM; ++t) wv += c7[t] * sc7[t];
+            if (wave == NW - 1) {        // the corners' rows: per-lane weights, private to this wave (LDS ops of a wave are in order)
+                const int cbase = (1 + lv.nface + lv.nedge) * NDIR;        // (the only rows in LDS: stored from W[0] on)
+                for (int idx = cbase + lane; idx < lv.ncls * NDIR; idx += 64) {
+                    double w = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NTERM; ++t) w += lv.ctab[(size_t)idx * NTERM + t] * sc7[t];
+                    W[idx - cbase] = w;
+                }
+            }
+        }
+        if (FUSED) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mq[q] = a.mult ? __builtin_amdgcn_readfirstlane(mqr[q]) : 0x01010101u;   // (no table: all 1)
+        }
+    };
+    if (EARLY) issue_rows();
     const double *xc = a.x + cell * lv.ld;
     double rr = 0.0, pap = 0.0;
     {
@@ -135,6 +237,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     if (FUSED) pw[q] = ccol ? lv.par32[t] : 0u;
                 }
             }
+            if (EARLY && q0 == 0) finish_tables();          // (the rows were requested before this batch's loads)
             if (FUSED && q0 == 0 && ccol && !cgather) {   // coarse column complete before the first use
                 if (tid < lv.nf_coarse) cs[tid] = cval;
                 __syncthreads();
@@ -183,89 +286,15 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // (scheduling fence: keeps the table prefetch below out of the load phase's register budget -- the
     //  1024-thread variants must stay within 64 VGPRs to keep two workgroups resident per CU)
     __builtin_amdgcn_sched_barrier(0);
-    // compact addressing words, fetched two iterations ahead of their use so that the L2 latency of
-    // the table never sits in a thread's dependent chain
-    const int m = lv.m;
-    const uint32_t dm = (a.flags & 1) ? dmask[cell] : 0u;
+    issue_words();
+    if (!EARLY) {
+        issue_rows();
+        finish_tables();
+    }
     const double *sc = a.src ? a.src + cell * lv.ld : nullptr;
     double *oc = a.out ? a.out + cell * lv.ld : nullptr;   // null: only the reductions of a FUSED pass are wanted
     const int nsurf = lv.off_int;
-    // (pos32 / sweep32 / sweep_slot carry TABLE_PAD entries of padding -- zero words, slot 0xffff -- so the
-    //  two-ahead prefetch needs no bounds checks and both loops have a wave-uniform trip count)
-    // RB: one entity class per wave.  NT/64/4 waves share a face (FI runs of 64 slots each), the edges are dealt to the
-    // waves from the last one backwards (NE per wave: 1 of 16 waves, 2 of 4), the last wave takes the corners instead
-    // of an interior block -- the 945 blocks of level 6 fill waves 0..14, the 152 of level 5 waves 0..2.
-    // 512-thread instantiation (three workgroups per CU): 2 waves per face with 4 runs each, the interior blocks in two passes
-    constexpr int NW = NT / 64, WPF = NW / 4 > 0 ? NW / 4 : 1, NE = NW >= 6 ? 1 : 2;
-    constexpr int FI = RB && NT == 512 ? 4 : 2;
-    constexpr int NPASS = RB && NT == 512 ? 2 : 1;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int face = wave / WPF, ft0 = (wave % WPF) * (FI * 64);
-    int edge[NE], ebase[NE];
-#pragma unroll
-    for (int q = 0; q < NE; ++q) {
-        edge[q] = NW - 1 - wave + q * NW;
-        if (edge[q] >= lv.nedge) edge[q] = -1;
-        ebase[q] = lv.off_edge + (edge[q] < 0 ? 0 : edge[q]) * lv.nei;
-    }
-    uint32_t fw[FI], ew[NE][1], cw = 0u;
-#pragma unroll
-    for (int q = 0; q < FI; ++q) fw[q] = 0u;
-    uint32_t p0 = 0u, p1 = 0u;
-    double wv = 0.0;                 // RB: lane d: interior weight d; lane 16 + d: this wave's face; lane 32 + 16 q + d: its edge q
-    if (RB) {
-#pragma unroll
-        for (int q = 0; q < FI; ++q) {
-            const int ti = ft0 + q * 64 + lane;
-            if (ti < lv.nfi) fw[q] = lv.pos32[lv.off_face + face * lv.nfi + ti];
-        }
-#pragma unroll
-        for (int q = 0; q < NE; ++q) ew[q][0] = edge[q] >= 0 && lane < lv.nei ? lv.pos32[ebase[q] + lane] : 0u;
-        if (wave == NW - 1 && lane < lv.ncorner) cw = lv.pos32[lane];
-        // class rows (L2-resident table) x the cell's 7 scales
-        int row = 0;
-        if (lane < 15)
-            row = lane;
-        else if (lane >= 16 && lane < 31)
-            row = (1 + face) * NDIR + lane - 16;
-        else if (lane >= 32 && lane < 47 && edge[0] >= 0)
-            row = (1 + lv.nface + edge[0]) * NDIR + lane - 32;
-        else if (NE > 1 && lane >= 48 && lane < 63 && edge[NE - 1] >= 0)
-            row = (1 + lv.nface + edge[NE - 1]) * NDIR + lane - 48;
-        double c7[NTERM], sc7[NTERM];
-#pragma unroll
-        for (int t = 0; t < NTERM; ++t) c7[t] = lv.ctab[(size_t)row * NTERM + t];
-#pragma unroll
-        for (int t = 0; t < NTERM - 1; ++t) sc7[t] = (a.flags & 2) ? 0.0 : a.alpha * readlane_f64(cv, t);
-        sc7[NTERM - 1] = a.alpha * a.lambda * ((a.flags & 16) ? 1.0 : readlane_f64(cv, NTERM - 1));
-#pragma unroll
-        for (int t = 0; t < NTERM; ++t) wv += c7[t] * sc7[t];
-        if (wave == NW - 1) {        // the corners' rows: per-lane weights, private to this wave (LDS ops of a wave are in order)
-            const int cbase = (1 + lv.nface + lv.nedge) * NDIR;        // (the only rows in LDS: stored from W[0] on)
-            for (int idx = cbase + lane; idx < lv.ncls * NDIR; idx += 64) {
-                double w = 0.0;
-#pragma unroll
-                for (int t = 0; t < NTERM; ++t) w += lv.ctab[(size_t)idx * NTERM + t] * sc7[t];
-                W[idx - cbase] = w;
-            }
-        }
-    } else {
-        p0 = lv.pos32[tid];
-        p1 = lv.pos32[tid + NT];
-    }
     const int nsw = RB ? lv.nblk : lv.nsweep;
-    const uint32_t *iw = RB ? lv.blk_word : lv.sweep32;
-    const uint16_t *is = RB ? lv.blk_slot : lv.sweep_slot;
-    uint32_t q0 = iw[tid];
-    uint32_t q1 = RB && NPASS < 2 ? 0u : iw[tid + NT];
-    int s0 = (int)is[tid];
-    int s1 = RB && NPASS < 2 ? 0 : (int)is[tid + NT];
-    uint32_t mq[4] = {0, 0, 0, 0};   // the cell's 16 entity multiplicities, wave-uniform -> SGPRs
-    if (FUSED) {
-        const uint32_t *mp = reinterpret_cast<const uint32_t *>(a.mult + cell * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mq[q] = a.mult ? __builtin_amdgcn_readfirstlane(mp[q]) : 0x01010101u;   // (no table: all 1)
-    }
     const bool wdot = WD && FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
     HMG_STAMP(2);   // tables requested, before the barrier
     __syncthreads();
