@@ -158,9 +158,7 @@ def main():
     ctx = hmg.Context(local_rank, stream=stream)
     if args.apply_threads is not None:
         ctx.set_option("apply_threads", args.apply_threads)
-    for kv in filter(None, os.environ.get("HMG_OPTIONS", "").split(",")):     # dev knobs, e.g. HMG_OPTIONS=fold_x=0
-        name, val = kv.split("=")
-        ctx.set_option(name, int(val))
+    # (dev knobs for A/B runs: HMG_OPTIONS=name=value,... is applied by hmg.Context itself)
 
     L = args.levels
     w = args.width

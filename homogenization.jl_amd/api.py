@@ -20,6 +20,7 @@ hierarchical layout.  There is no CPU implementation behind these calls.
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from dataclasses import dataclass
 
@@ -62,6 +63,9 @@ class Context:
         self.device = device
         self._keepalive = []      # caller-side memory the library points into (e.g. a scalar bank tensor)
         self._fin = weakref.finalize(self, self._lib.hmg_ctx_destroy, h)
+        for kv in filter(None, os.environ.get("HMG_OPTIONS", "").split(",")):   # dev knobs for A/B runs, e.g. HMG_OPTIONS=fold_x=0
+            name, val = kv.split("=")
+            self.set_option(name, int(val))
 
     def stream_handle(self) -> int:
         """The context's hipStream_t as an integer (0 = the null stream): foreign collectives must be issued on it."""
