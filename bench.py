@@ -256,7 +256,10 @@ def main():
                        "setup_seconds": setup_seconds,
                        "residual_norm_after": rnorm},
             "roofline": {"bound": "hbm",
-                         "kernel": "hmg::k_apply<3,512,13,*,6> (finest-level operator apply, three 512-thread workgroups per CU; per V-cycle: 1 residual, 6 fused CG passes, 2 residuals with the pending x-updates / the prolongation folded in)",
+                         "kernel": ("hmg::k_apply<3,512,13,*,6> (finest-level operator apply, three 512-thread workgroups per CU"
+                                    if L == 6 else "hmg::k_apply_slab<3,1024,*> (finest-level operator apply, rolling LDS window"
+                                    if L == 7 else "hmg::k_apply (finest-level operator apply") +
+                                   "; per V-cycle: 1 residual, 6 fused CG passes, 2 residuals with the pending x-updates / the prolongation folded in)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
