@@ -26,6 +26,7 @@ SIGNATURES = {
     "hmg_ctx_create_on_stream": (c_int, [c_int, vp, pp]),
     "hmg_ctx_destroy": (c_int, [vp]),
     "hmg_ctx_sync": (c_int, [vp]),
+    "hmg_ctx_release_memory": (c_int, [vp]),
     "hmg_ctx_set_option": (c_int, [vp, ctypes.c_char_p, c_i64]),
     "hmg_ctx_set_option_f64": (c_int, [vp, ctypes.c_char_p, c_f64]),
     "hmg_ctx_scalar_bank": (vp, [vp]),

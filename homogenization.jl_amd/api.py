@@ -97,6 +97,10 @@ class Context:
     def sync(self):
         L.check(self._lib.hmg_ctx_sync(self.h))
 
+    def release_memory(self):
+        """Hand the pooled blocks of destroyed level vectors back to the device (hmg_ctx_release_memory)."""
+        L.check(self._lib.hmg_ctx_release_memory(self.h))
+
     def set_option(self, name: str, value):
         if isinstance(value, float):
             L.check(self._lib.hmg_ctx_set_option_f64(self.h, name.encode(), value))

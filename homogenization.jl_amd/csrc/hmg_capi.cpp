@@ -1484,6 +1484,14 @@ int hmg_ctx_sync(hmg_ctx *ctx)
     HMG_END
 }
 
+int hmg_ctx_release_memory(hmg_ctx *ctx)
+{
+    HMG_TRY
+    need(ctx != nullptr, "null ctx");
+    vec_pool_trim(ctx);
+    HMG_END
+}
+
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
 {
     HMG_TRY

@@ -44,6 +44,9 @@ int hmg_ctx_create(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_create_on_stream(int device, void *stream, hmg_ctx **out);
 int hmg_ctx_destroy(hmg_ctx *ctx);
 int hmg_ctx_sync(hmg_ctx *ctx);
+/* Hands the blocks of destroyed level vectors that the context keeps for reuse (option "vec_pool") back to the device;
+ * done automatically when an allocation of a level vector fails and when the context goes. */
+int hmg_ctx_release_memory(hmg_ctx *ctx);
 /* option names: "apply_threads" (workgroup size of the apply kernel, 0 = auto), "apply_wg512" (1 = default: level-6
  * cells -- 6545 nodes, 52 KB of LDS -- are applied by 512-thread workgroups, three resident per CU; 0 = by 1024-thread
  * workgroups, two per CU; same arithmetic per node), "fuse_cg" (1 = fused CG pass,

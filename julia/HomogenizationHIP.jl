@@ -34,6 +34,7 @@ mutable struct HipContext
     end
 end
 sync(c::HipContext) = check(ccall((:hmg_ctx_sync, LIB), Cint, (Ptr{Cvoid},), c.h))
+release_memory(c::HipContext) = check(ccall((:hmg_ctx_release_memory, LIB), Cint, (Ptr{Cvoid},), c.h))
 set_option!(c::HipContext, name::String, v::Integer) =
     check(ccall((:hmg_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Int64), c.h, name, v))
 
