@@ -220,7 +220,34 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             v += 0.5 * cs[pa];
             return v + 0.5 * cs[pb];
         };
+        // A fused pass that reads nothing but its own column (CG step 0 with r itself as p: no x2 / xacc / x3 / coarse
+        // column) takes the whole column in ONE batch like the plain apply -- one memory round trip instead of two.
+        const bool light = FUSED && NT >= 512 && !x2c && !xac && !x3c && !ccol;   // (level 5, 256 threads: the extra path costs a resident workgroup)
+        if (FUSED && light) {
+            double xv[SPT];
+            int lp[SPT];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                if (t < nf) {
+                    xv[q] = xc[t];
+                    lp[q] = lv.lpos[t];
+                }
+            }
+            if (EARLY) finish_tables();
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                if (t < nf) {
+                    const double v = xv[q];
+                    if (xoc) xoc[t] = v;
+                    rr += v * v;
+                    xs[lp[q]] = v;
+                }
+            }
+        }
         constexpr int HB = FUSED ? (SPT + 1) / 2 : SPT;
+        if (!light) {
 #pragma unroll
         for (int q0 = 0; q0 < SPT; q0 += HB) {
             double xv[HB], x2v[HB], xav[HB];
@@ -262,6 +289,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     xs[lp[q]] = v;
                 }
             }
+        }
         }
         for (int t = tid + SPT * NT; t < nf; t += NT) {   // only for cells larger than SPT*NT
             double v = xc[t];
