@@ -663,6 +663,12 @@ def test_handles_may_be_destroyed_in_any_order(oracle):
     c = hmg.DeviceMatrix(g, 3)
     assert c.device_ptr() == ptr_b and not c.to_host().any()
     c.fill(3.0)
+    d = hmg.DeviceMatrix(g, 2)
+    d.close()
+    ctx.release_memory()                          # hmg_ctx_release_memory: the pooled block of d goes back to the device
+    d = hmg.DeviceMatrix(g, 2)
+    assert not d.to_host().any()
+    d.close()
     n = a.shape[0] * a.shape[1]
     ctx.close()                                   # the caller's reference only
     assert g.ncells() == m.nelements()            # the grid still answers
