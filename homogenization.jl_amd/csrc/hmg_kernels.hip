@@ -246,8 +246,32 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 }
             }
         }
+        // ... and the dead step of a pre-smoother (reads r and p, forms p_new only in LDS, writes nothing): two streams
+        const bool light2 = FUSED && NT >= 512 && x2c && !xoc && !xac && !x3c && !ccol;
+        if (FUSED && light2) {
+            double xv[SPT], x2v[SPT];
+            int lp[SPT];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                if (t < nf) {
+                    xv[q] = xc[t];
+                    x2v[q] = x2c[t];
+                    lp[q] = lv.lpos[t];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                if (t < nf) {
+                    const double v = xv[q] + beta * x2v[q];
+                    rr += v * v;
+                    xs[lp[q]] = v;
+                }
+            }
+        }
         constexpr int HB = FUSED ? (SPT + 1) / 2 : SPT;
-        if (!light) {
+        if (!light && !light2) {
 #pragma unroll
         for (int q0 = 0; q0 < SPT; q0 += HB) {
             double xv[HB], x2v[HB], xav[HB];
