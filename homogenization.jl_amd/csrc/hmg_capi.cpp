@@ -29,6 +29,8 @@ using namespace hmg;
 
 namespace {
 
+void release_pooled_memory();   // every live context hands its pooled level-vector blocks back (defined behind hmg_ctx)
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -47,7 +49,12 @@ struct DevBuf {
     {
         release();
         n = count;
-        if (count) HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        if (!count) return;
+        if (hipMalloc((void **)&p, count * sizeof(T)) != hipSuccess) {
+            (void)hipGetLastError();
+            release_pooled_memory();             // blocks the contexts keep for reuse may be what is in the way
+            HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        }
     }
     void upload(const std::vector<T> &h, hipStream_t s)
     {
@@ -140,6 +147,17 @@ void vec_pool_trim(hmg_ctx *c)
     c->vec_pool.clear();
 }
 
+std::vector<hmg_ctx *> &live_contexts()
+{
+    static std::vector<hmg_ctx *> v;
+    return v;
+}
+
+void release_pooled_memory()
+{
+    for (hmg_ctx *c : live_contexts()) vec_pool_trim(c);
+}
+
 // zero-filled device memory for one level vector (stream-ordered: kernels of the previous owner were enqueued on the
 // same stream, or joined to it by events, before the block came back)
 double *vec_alloc(hmg_ctx *c, size_t bytes)
@@ -154,7 +172,7 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
         }
     if (!p && hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
-        vec_pool_trim(c);                        // blocks of other sizes may be what is in the way
+        release_pooled_memory();                 // pooled blocks of other sizes (any context's) may be what is in the way
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess)
             throw std::runtime_error(std::string("hipMalloc of a level vector (") + std::to_string(bytes >> 20) +
@@ -1389,6 +1407,8 @@ int comm_exchange_end(void *user)
 static void ctx_unref(hmg_ctx *ctx)
 {
     if (!ctx || --ctx->refs > 0) return;
+    auto &lc = live_contexts();
+    lc.erase(std::remove(lc.begin(), lc.end(), ctx), lc.end());
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->timer.pool) {
@@ -1465,6 +1485,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_unblocked = 0;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
     c->L.apply_pipe = 0;   // experimental (measured slower than k_apply inside the V-cycle)
+    live_contexts().push_back(c.get());
     *out = c.release();
     HMG_END
 }
