@@ -48,6 +48,33 @@ def test_operator_properties_full_size(prob):
     assert np.sqrt(hmg.dot(az, az)) <= 1e-12 * np.sqrt(hmg.dot(ay, ay))
 
 
+def test_workgroup_shapes_agree_full_size(prob):
+    """The two level-6 instantiations (three 512-thread workgroups per CU / two of 1024 threads, option apply_wg512)
+    evaluate every node with the same operands in the same order: at full size the outputs of the plain apply and of a
+    residual with a source vector are equal to the last bit."""
+    ctx, g, A = prob
+    x = hmg.DeviceMatrix(g, L).rand(11)
+    b = hmg.DeviceMatrix(g, L).rand(12)
+    outs = []
+    for wg in (1, 0):
+        ctx.set_option("apply_wg512", wg)
+        try:
+            y = hmg.DeviceMatrix(g, L)
+            hmg.apply_ex(1.0, g, x, None, y, constrain=True)
+            r = hmg.DeviceMatrix(g, L)
+            hmg.apply_ex(-1.0, g, x, b, r, constrain=True)
+            outs.append((y, r))
+        finally:
+            ctx.set_option("apply_wg512", 1)
+    (y1, r1), (y0, r0) = outs
+    hmg.axpy(-1.0, y1, y0)                       # y0 - y1
+    hmg.axpy(-1.0, r1, r0)
+    assert hmg.dot(y0, y0) == 0.0 and hmg.dot(r0, r0) == 0.0
+    assert hmg.dot(y1, y1) > 0.0
+    for v in (y0, y1, r0, r1, x, b):
+        v.close()
+
+
 def test_constants_and_mass_full_size(prob):
     ctx, g, A = prob
     one = hmg.DeviceMatrix(g, L).fill(1.0)
