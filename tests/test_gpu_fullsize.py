@@ -130,3 +130,36 @@ def test_vcycle_contracts_full_size(prob):
         norms.append(hmg.norm_unique(top.r))
     assert all(np.isfinite(norms))
     assert all(b < 0.7 * a for a, b in zip(norms, norms[1:])), norms
+
+
+def test_dead_tails_leave_x_and_r_untouched_full_size(prob):
+    """hmg_vcycle with and without the dead tails of the smoothers (options lean_post, lazy_dead, fold_x: what the library
+    skips is work whose results the reference's own control flow overwrites before reading): x and r of the finest level
+    after two V-cycles are equal to the last bit."""
+    ctx, g, A = prob
+    base = hmg.BaseLevel(g)
+    res = []
+    for on in (1, 0):
+        for o in ("lean_post", "lazy_dead", "fold_x"):
+            ctx.set_option(o, on)
+        try:
+            states = [hmg.LevelState(g, i + 1) for i in range(L)]
+            top = states[-1]
+            top.x.rand(21)
+            hmg.broadcast_interfaces(top.x, g, L)
+            hmg.apply_constraint(top.x, L, g)
+            hmg.rhs_axi_grad_v(top.b, g, driver.random_unit_vec(3))
+            for _ in range(2):
+                hmg.vcycle(g, base, [A] * L, states, L, 3)
+            res.append(states)
+        finally:
+            for o in ("lean_post", "lazy_dead", "fold_x"):
+                ctx.set_option(o, 1)
+    a, b = res[0][-1], res[1][-1]
+    assert hmg.dot(a.x, a.x) > 0.0
+    hmg.axpy(-1.0, a.x, b.x)
+    hmg.axpy(-1.0, a.r, b.r)
+    assert hmg.dot(b.x, b.x) == 0.0 and hmg.dot(b.r, b.r) == 0.0
+    for states in res:
+        for st in states:
+            st.close()
