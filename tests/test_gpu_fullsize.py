@@ -132,15 +132,20 @@ def test_vcycle_contracts_full_size(prob):
     assert all(b < 0.7 * a for a, b in zip(norms, norms[1:])), norms
 
 
-def test_dead_tails_leave_x_and_r_untouched_full_size(prob):
-    """hmg_vcycle with and without the dead tails of the smoothers (options lean_post, lazy_dead, fold_x: what the library
-    skips is work whose results the reference's own control flow overwrites before reading): x and r of the finest level
-    after two V-cycles are equal to the last bit."""
+EXACT = ("lean_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_gather", "fold_faces")
+
+
+def test_exact_savings_leave_x_and_r_untouched_full_size(prob):
+    """hmg_vcycle with and without every exact saving of the library -- the dead tails of the smoothers (lean_post,
+    lazy_dead, fold_x: work whose results the reference's own control flow overwrites before reading), r taken as p by
+    exchanging handles (swap_rp), the prolongation folded into the post-smoother's first residual (fold_prolong,
+    prolong_gather), the face sums of A p formed inside the r-update (fold_faces): x and r of the finest level after two
+    V-cycles are equal to the last bit."""
     ctx, g, A = prob
     base = hmg.BaseLevel(g)
     res = []
     for on in (1, 0):
-        for o in ("lean_post", "lazy_dead", "fold_x"):
+        for o in EXACT:
             ctx.set_option(o, on)
         try:
             states = [hmg.LevelState(g, i + 1) for i in range(L)]
@@ -153,7 +158,7 @@ def test_dead_tails_leave_x_and_r_untouched_full_size(prob):
                 hmg.vcycle(g, base, [A] * L, states, L, 3)
             res.append(states)
         finally:
-            for o in ("lean_post", "lazy_dead", "fold_x"):
+            for o in EXACT:
                 ctx.set_option(o, 1)
     a, b = res[0][-1], res[1][-1]
     assert hmg.dot(a.x, a.x) > 0.0
