@@ -28,7 +28,7 @@ def test_apply_matches_oracle_on_sampled_cells_full_size(prob, oracle):
     """The operator apply is cell-local (src/apply_local_operators.jl:85-133): at BASELINE config 3's full size the columns
     of 16 sampled cells (first, last, random) of y = alpha A x are compared with the oracle's 10 CSC passes on exactly
     those cells -- same geometry, same sigma, same x (the hashed fill has a numpy twin) -- at the tolerance of the small
-    cases, 1e-11."""
+    cases, 1e-11; likewise restrict_to! and interpolate_and_sum_to! between levels 6 and 5."""
     ctx, g, A = prob
     O = oracle
     ne = g.ncells()
@@ -48,6 +48,24 @@ def test_apply_matches_oracle_on_sampled_cells_full_size(prob, oracle):
     want = np.zeros_like(xs, order="F")
     O.mul(-1.3, sub, Ao, xs, want)
     assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    # the level transfers are cell-local too (src/interpolation.jl:52-74): restriction 1e-14, prolongation bit for bit
+    P = O.ImplicitFineGrid.create(O.hypercube(3, 1), L).reference.interops[L - 2]
+    nfc = g.nf(L - 1)
+    xf = hmg.DeviceMatrix(g, L).rand(78)
+    xc = hmg.DeviceMatrix(g, L - 1).rand(79)
+    rc = hmg.DeviceMatrix(g, L - 1)
+    hmg.restrict_to(rc, g, xf)
+    hmg.interpolate_and_sum_to(xf, g, xc)
+    got_r, got_p = rc.to_host()[:, cells], xf.to_host()[:, cells]
+    for v in (xf, xc, rc):
+        v.close()
+    f0 = np.asfortranarray(np.concatenate([hmg.host_random((nf, 1), 78, cell_offset=int(c)) for c in cells], axis=1))
+    c0 = np.asfortranarray(np.concatenate([hmg.host_random((nfc, 1), 79, cell_offset=int(c)) for c in cells], axis=1))
+    want_r = np.zeros_like(c0, order="F")
+    O.restrict_to(want_r, P, f0)
+    assert np.abs(got_r - want_r).max() <= 1e-14 * np.abs(want_r).max()
+    O.interpolate_and_sum_to(f0, P, c0)
+    np.testing.assert_array_equal(got_p, f0)
 
 
 def test_operator_properties_full_size(prob):
