@@ -104,6 +104,24 @@ def cpu_time_to_tolerance(hmg, driver, n, refinements, tolerance, max_seconds):
             "cores": int(O.available_cores()), "kind": "port"}
 
 
+def launcher_command(ngpus, argv, port):
+    """The torch.distributed.run command line `python bench.py --gpus N ...` turns itself into (one rank per GPU, RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(ngpus, argv):
+    import socket
+    import subprocess
+    with socket.socket() as s:              # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this platform (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(launcher_command(ngpus, argv, port), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +138,12 @@ def main():
                     help="time limit of the CPU oracle's run of the driver on BASELINE config 2")
     ap.add_argument("--apply-threads", type=int, default=None)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  The ranks are CHILD processes of
+        # torch.distributed.run, started before this process has imported torch or touched HIP (no exec of a process
+        # that holds the GPU); their stdout (rank 0's JSON line) and stderr pass straight through.
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     # Only the JSON line goes to this process's stdout: libraries underneath write there too (RCCL prints a version
     # banner when a communicator is created, gloo its rank-connection lines), so file descriptor 1 points at stderr until
