@@ -168,7 +168,12 @@ def main():
     if os.environ.get("HMG_SINGLE_DEVICE") == "1":      # rehearsal of the N>1 path on a 1-GPU box (gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    force_part = os.environ.get("HMG_FORCE_PARTITIONED") == "1"   # rehearsal: partitioned code path on any world size
+    # single-GPU rehearsals of the partitioned code path (dist.partitioned_checkerboard): HMG_SYNTHETIC_CUT=planes cuts the
+    # one block at its three mid-planes (results bit-identical with the unpartitioned run), HMG_REHEARSE_WORLD=8 holds
+    # rank 0's share of the 8-rank brick (timing only); HMG_OVERLAP=0 switches the overlapped exchange off
+    synthetic_cut = os.environ.get("HMG_SYNTHETIC_CUT") == "planes"
+    rehearse_world = int(os.environ.get("HMG_REHEARSE_WORLD", "0")) or None
+    force_part = os.environ.get("HMG_FORCE_PARTITIONED") == "1" or synthetic_cut or rehearse_world is not None
     dist = None
     if world > 1 or force_part:
         import torch.distributed as dist
@@ -189,9 +194,16 @@ def main():
     t_setup0 = time.perf_counter()
     if world > 1 or force_part:
         from homogenization_jl_amd import dist as hdist
-        prob = hdist.partitioned_checkerboard(ctx, w, L, world, rank, seed=0, values=(1.0, args.sigma_high))
+        prob = hdist.partitioned_checkerboard(ctx, w, L, world, rank, seed=0, values=(1.0, args.sigma_high),
+                                              synthetic_cut=synthetic_cut, rehearse_world=rehearse_world)
+        if os.environ.get("HMG_OVERLAP") == "0":
+            prob.exchange.set_overlap(prob.implicit, False)
         base, cond, implicit, op = prob.base, prob.cond, prob.implicit, prob.op
         workload = f"3D Tet64 checkerboard, {prob.global_shape} unit cubes over {world} GPUs ({w}^3 per GPU), refinements={L - 1}"
+        if synthetic_cut:
+            workload += " [REHEARSAL: partitioned code path on one rank, block cut at its three mid-planes]"
+        if rehearse_world:
+            workload += f" [REHEARSAL: rank 0's share of the {rehearse_world}-rank partition alone, sums over ranks incomplete: timing only]"
     else:
         base, cond, implicit, op = driver.checkerboard_problem(ctx, hmg.Tet64, w, L, seed=0,
                                                                values=(1.0, args.sigma_high))

@@ -95,6 +95,7 @@ SIGNATURES = {
     "hmg_block_owner": (c_int, [c_int, c_i64, p_f64, c_i64, p_i64, p_i64, c_f64, p_f64, p_i32]),
     "hmg_conductivity_per_element": (c_int, [c_int, c_i64, p_f64, c_i64, p_i64, p_i64, p_f64, p_f64, p_f64]),
     "hmg_grid_create_partition": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, p_i32, c_int, c_int, pp]),
+    "hmg_grid_create_partition_rehearsal": (c_int, [vp, c_int, c_int, c_i64, p_f64, c_i64, p_i64, p_i32, p_i32, c_int, c_int, pp]),
 }
 
 _lib = None

@@ -135,6 +135,10 @@ struct hmg_ctx {
     // 0.001 s fresh, 2.05 s after a hipFree), i.e. 1.9 s of the 71 GB a second driver call allocates.
     bool vec_pool_on = true;
     std::vector<std::pair<size_t, void *>> vec_pool;
+    // rehearsal on fewer GPUs than the partition is meant for: a grid that holds rank r's share of an N-rank partition
+    // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
+    // the work per rank, the message sizes and the stream choreography are the real ones, the numbers are not)
+    bool comm_rehearsal = false;
 };
 
 namespace {
@@ -243,7 +247,7 @@ struct hmg_grid {
     // inputs of the partition analysis, kept for a domain shrink (re-analysis of the prefix mesh)
     std::vector<double> part_coords;
     std::vector<int64_t> part_cells;
-    std::vector<int32_t> part_owner;
+    std::vector<int32_t> part_owner, part_cut_owner;     // (part_cut_owner: rehearsal partitions only, else empty)
     int64_t part_nnodes = 0, part_ncells = 0;
     DevBuf<int32_t> d_nodes_g, d_owned, d_cells_gnode;
     CutKind cut[3];   // faces, edges, nodes
@@ -338,7 +342,7 @@ void upload_mesh(hmg_grid *g)
     g->d_face_pairs.upload(M.face_pairs, s);
     {
         std::vector<int32_t> fp((size_t)M.ncells * 4, -1);
-        for (size_t q = 0; q + 2 < M.face_pairs.size(); q += 3) {
+        for (size_t q = 3 * (size_t)M.ncut_face_pairs; q + 2 < M.face_pairs.size(); q += 3) {   // (cut pairs never ride in the r-update)
             const int32_t ca = M.face_pairs[q], cb = M.face_pairs[q + 1], la = M.face_pairs[q + 2] & 15, lb = M.face_pairs[q + 2] >> 4;
             fp[(size_t)ca * 4 + la] = (cb << 2) | lb;
             fp[(size_t)cb * 4 + lb] = (ca << 2) | la;
@@ -386,6 +390,7 @@ void upload_mesh(hmg_grid *g)
     d.ncells_inner = (int64_t)M.cells_inner.size();
     d.ncut_edge_groups = M.ncut_edge_groups;
     d.ncut_node_groups = M.ncut_node_groups;
+    d.ncut_face_pairs = M.ncut_face_pairs;
     d.coef = g->d_coef.p;
 }
 
@@ -1549,6 +1554,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->lean_post = value != 0;
     else if (n == "prolong_gather")
         ctx->prolong_gather = value != 0;
+    else if (n == "comm_rehearsal")
+        ctx->comm_rehearsal = value != 0;
     else if (n == "vec_pool") {
         ctx->vec_pool_on = value != 0;
         if (!ctx->vec_pool_on) vec_pool_trim(ctx);
@@ -1648,8 +1655,9 @@ static void finish_partition(hmg_grid *g)
     g->d_cells_gnode.upload(cg, g->ctx->stream);
 }
 
-int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
-                              const int64_t *cells, const int32_t *owner, int rank, int nranks, hmg_grid **out)
+static int create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
+                            const int64_t *cells, const int32_t *owner, const int32_t *cut_owner, int rank, int nranks,
+                            hmg_grid **out)
 {
     HMG_TRY
     need(coords && cells && owner && out, "null argument");
@@ -1661,10 +1669,11 @@ int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes
     g->nlevels = nlevels;
     g->lt = build_level_tables(dim, nlevels);
     g->part.reset(new Partition);
-    build_partition(dim, nnodes, coords, ncells, cells, owner, rank, nranks, g->mesh_full, *g->part);
+    build_partition(dim, nnodes, coords, ncells, cells, owner, rank, nranks, g->mesh_full, *g->part, cut_owner);
     g->part_coords.assign(coords, coords + (size_t)dim * nnodes);
     g->part_cells.assign(cells, cells + (size_t)(dim + 1) * ncells);
     g->part_owner.assign(owner, owner + ncells);
+    if (cut_owner) g->part_cut_owner.assign(cut_owner, cut_owner + ncells);
     g->part_nnodes = nnodes;
     g->part_ncells = ncells;
     upload_levels(g.get());
@@ -1673,6 +1682,19 @@ int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes
     if (ctx) ctx->refs += 1;
     *out = g.release();
     HMG_END
+}
+
+int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
+                              const int64_t *cells, const int32_t *owner, int rank, int nranks, hmg_grid **out)
+{
+    return create_partition(ctx, dim, nlevels, nnodes, coords, ncells, cells, owner, nullptr, rank, nranks, out);
+}
+
+int hmg_grid_create_partition_rehearsal(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords,
+                                        int64_t ncells, const int64_t *cells, const int32_t *owner, const int32_t *cut_owner,
+                                        int rank, int nranks, hmg_grid **out)
+{
+    return create_partition(ctx, dim, nlevels, nnodes, coords, ncells, cells, owner, cut_owner, rank, nranks, out);
 }
 
 int hmg_grid_destroy(hmg_grid *grid)
@@ -1719,7 +1741,8 @@ int hmg_grid_shrink(hmg_grid *g, int64_t ncells_prefix, int64_t nnodes_prefix)
         std::unique_ptr<Partition> np(new Partition);
         MeshTables local;
         build_partition(g->dim, nnodes_prefix, g->part_coords.data(), ncells_prefix, g->part_cells.data(),
-                        g->part_owner.data(), rank, nranks, local, *np);
+                        g->part_owner.data(), rank, nranks, local, *np,
+                        g->part_cut_owner.empty() ? nullptr : g->part_cut_owner.data());
         need(local.ncells <= g->mesh_full.ncells, "shrunk partition is larger than the original one");
         g->mesh = std::move(local);
         g->part = std::move(np);
@@ -1787,7 +1810,9 @@ int hmg_grid_table_i32(const hmg_grid *g, int level, const char *which, int32_t 
     } else if (w == "cut_counts") {
         need(g->part != nullptr, "not a partitioned grid");
         tmp = {(int32_t)g->part->nglobal[0], (int32_t)g->part->nglobal[1], (int32_t)g->part->nglobal[2],
-               (int32_t)g->part->gid[0].size(), (int32_t)g->part->gid[1].size(), (int32_t)g->part->gid[2].size()};
+               (int32_t)g->part->gid[0].size(), (int32_t)g->part->gid[1].size(), (int32_t)g->part->gid[2].size(),
+               (int32_t)g->cur().ncut_face_pairs, (int32_t)g->cur().ncut_edge_groups, (int32_t)g->cur().ncut_node_groups,
+               (int32_t)g->cur().cells_cut.size(), (int32_t)g->cur().cells_inner.size()};
         src = &tmp;
     } else if (w == "cut_gid_faces" || w == "cut_gid_edges" || w == "cut_gid_nodes" || w == "cut_ent_faces" ||
                w == "cut_ent_edges" || w == "cut_ent_nodes") {
@@ -2465,7 +2490,7 @@ int hmg_grid_use_comm(hmg_grid *g)
     need(g && g->ctx, "null grid or host-only grid");
     need(g->ctx->comm != nullptr, "hmg_comm_init must be called on the grid's context first");
     need(g->part != nullptr, "not a partitioned grid (hmg_grid_create_partition)");
-    need(g->part->nranks == g->ctx->comm_nranks && g->part->rank == g->ctx->comm_rank,
+    need(g->ctx->comm_rehearsal || (g->part->nranks == g->ctx->comm_nranks && g->part->rank == g->ctx->comm_rank),
          "the grid's partition and the context's communicator disagree on rank / size");
     const int64_t cap = std::max<int64_t>(hmg_grid_cut_buffer_doubles(g, 0), 1);
     g->own_exbuf.alloc((size_t)cap);

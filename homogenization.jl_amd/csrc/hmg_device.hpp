@@ -63,6 +63,7 @@ struct MeshDev {
     const uint16_t *dmask, *dupmask;
     const double *coef;          // 8 per cell
     int64_t ncut_edge_groups, ncut_node_groups;   // leading groups of the edge / node CSR that are cut
+    int64_t ncut_face_pairs;                      // leading face pairs that count as cut (rehearsal partitions only, else 0)
     const int32_t *cells_cut, *cells_inner;       // partitioned grids: cell lists for the overlapped exchange
     int64_t ncells_cut, ncells_inner;
     const uint8_t *mult;         // 16 per cell: number of copies of each entity (bit order of the masks)
@@ -144,8 +145,8 @@ void launch_apply_fused_kernel(const Launch &L, const LevelDev &lv, const MeshDe
 void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pap, int slot_rr);
 void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);
 
-// which: 0 everything; 1 only the cut edge / node groups; 2 everything else (faces, non-cut groups)
-// faces = false leaves the shared faces alone (their sum then rides in launch_cg_rupdate_faces)
+// which: 0 everything; 1 only the cut edge / node groups (and cut face pairs); 2 everything else (faces, non-cut groups)
+// faces = false leaves the non-cut shared faces alone (their sum then rides in launch_cg_rupdate_faces)
 void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which = 0,
                           bool faces = true);
 void launch_mask(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which /*0 dmask,1 dupmask*/);

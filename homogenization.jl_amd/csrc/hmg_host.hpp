@@ -157,6 +157,9 @@ struct MeshTables {
     // first (ncut_*_groups of them); cells_cut = local cells that own a copy of any cut entity,
     // cells_inner = the others.  Used to overlap the exchange with the work that does not feed it.
     int64_t ncut_edge_groups = 0, ncut_node_groups = 0;
+    // ... and shared faces whose BOTH copies are local although the face counts as cut (only with a rehearsal's
+    // `cut_owner`, see build_partition: in a real partition a cut face has one local copy and is no face pair at all)
+    int64_t ncut_face_pairs = 0;
     std::vector<int32_t> cells_cut, cells_inner;
 
     // cell geometry: detJ and Jinv = inv(J') (column-major dim x dim)
@@ -208,8 +211,13 @@ struct Partition {
 
 // Splits `global` by owner[cell] and fills `local` (tables of this rank's cells, with Dirichlet mask,
 // duplicate mask and multiplicities taken from the GLOBAL mesh) and `part`.
+// cut_owner (optional, rehearsals on fewer GPUs than the partition is meant for): an entity counts as cut when its
+// copies' cells differ in cut_owner[] instead of owner[] -- with owner = 0 everywhere and cut_owner = the octant of a
+// cell, one rank walks the cut-first cell lists, the pack / unpack kernels and the exchange of an 8-rank partition while
+// holding every copy itself (the sum over ranks is then the identity and the results equal the unpartitioned ones).
 void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells_1based,
-                     const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part);
+                     const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part,
+                     const int32_t *cut_owner = nullptr);
 
 std::string &last_error();
 

@@ -911,11 +911,18 @@ k_iface_csr(const int32_t *__restrict__ eptr, const int32_t *__restrict__ eent, 
 void launch_interface_sum(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double *x, int which, bool faces)
 {
     const int cap = L.num_cu * 8;
-    if (faces && which != 1 && lv.dim == 3 && lv.nfi > 0 && mesh.nfacepairs > 0) {
-        const int64_t blocks = (mesh.nfacepairs + 3) / 4;     // one wave per pair, blocks dispatched in pair order
-        hipLaunchKernelGGL(k_iface_faces, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.face_pairs,
-                           mesh.nfacepairs, lv.nfi, lv.off_face, lv.ld, x);
-        check_launch();
+    if (lv.dim == 3 && lv.nfi > 0 && mesh.nfacepairs > 0) {
+        // pairs [0, ncut) count as cut (rehearsal partitions): summed with the cut groups, whatever `faces` says
+        const int64_t ncut = mesh.ncut_face_pairs;
+        const int64_t first = which == 2 ? ncut : 0;
+        const int64_t last = which == 1 || !faces ? ncut : mesh.nfacepairs;
+        const int64_t np = last - first;
+        if (np > 0) {
+            const int64_t blocks = (np + 3) / 4;              // one wave per pair, blocks dispatched in pair order
+            hipLaunchKernelGGL(k_iface_faces, dim3((unsigned)blocks), dim3(256), 0, L.stream, mesh.face_pairs + 3 * first, np,
+                               lv.nfi, lv.off_face, lv.ld, x);
+            check_launch();
+        }
     }
     // group ranges of the CSR lists: [0, ncut) are cut by the partition, [ncut, n) are not
     auto range = [&](int64_t n, int64_t ncut, int64_t &first, int64_t &count) {

@@ -314,8 +314,10 @@ void restrict_mesh_tables(const MeshTables &full, int64_t ncells_prefix, int64_t
 }
 
 void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells_1based,
-                     const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part)
+                     const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part,
+                     const int32_t *cut_owner)
 {
+    const int32_t *cown = cut_owner ? cut_owner : owner;
     part.rank = rank;
     part.nranks = nranks;
     MeshTables &G = part.global;
@@ -394,7 +396,7 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
         for_groups(ents, [&](size_t i, size_t j) {
             bool cut = false;
             for (size_t q = i + 1; q < j; ++q)
-                if (owner[ents[q].cell] != owner[ents[i].cell]) cut = true;
+                if (cown[ents[q].cell] != cown[ents[i].cell]) cut = true;
             if (!cut) return;
             const int64_t id = part.nglobal[kind]++;
             for (size_t q = i; q < j; ++q)
@@ -406,6 +408,22 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
     }
     local.ncut_edge_groups = cut_first(local.edge_ptr, local.edge_ent, part.cell_lid[1]);
     local.ncut_node_groups = cut_first(local.node_ptr, local.node_ent, part.cell_lid[2]);
+    {
+        // cut faces with both copies on this rank (rehearsal with cut_owner only): first in the pair list -- they are
+        // summed with the cut edge / node groups, before the pack, and never ride in the CG r-update
+        std::unordered_set<int32_t> cs(part.cell_lid[0].begin(), part.cell_lid[0].end());
+        std::vector<int32_t> fp;
+        fp.reserve(local.face_pairs.size());
+        local.ncut_face_pairs = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (size_t q = 0; q + 2 < local.face_pairs.size(); q += 3) {
+                const bool is_cut = cs.count(local.face_pairs[q] * 8 + (local.face_pairs[q + 2] & 15)) != 0;
+                if (is_cut != (pass == 0)) continue;
+                fp.insert(fp.end(), local.face_pairs.begin() + q, local.face_pairs.begin() + q + 3);
+                if (pass == 0) ++local.ncut_face_pairs;
+            }
+        local.face_pairs.swap(fp);
+    }
     std::vector<uint8_t> is_cut_cell(part.cells_g.size(), 0);
     for (int kind = 0; kind < 3; ++kind)
         for (int32_t v : part.cell_lid[kind]) is_cut_cell[v >> 3] = 1;

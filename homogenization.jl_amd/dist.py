@@ -27,7 +27,9 @@ from . import api, driver
 class PartitionedGrid(api.ImplicitFineGrid):
     """ImplicitFineGrid over the cells `owner == rank` of a global base mesh."""
 
-    def __init__(self, ctx, base: api.Mesh, levels: int, owner, rank: int, nranks: int):
+    def __init__(self, ctx, base: api.Mesh, levels: int, owner, rank: int, nranks: int, cut_owner=None):
+        """cut_owner (rehearsals only, see hmg_grid_create_partition_rehearsal): which entities count as cut is decided by
+        cut_owner[] while owner[] still decides which cells are local."""
         self._lib = L.load()
         self.ctx = ctx
         self.global_base = base
@@ -38,10 +40,18 @@ class PartitionedGrid(api.ImplicitFineGrid):
         own = np.ascontiguousarray(owner, dtype=np.int32)
         assert own.shape == (cells.shape[0],)
         h = ctypes.c_void_p()
-        L.check(self._lib.hmg_grid_create_partition(ctx.h if ctx else None, base.dim, levels, nodes.shape[0],
-                                                    nodes.ctypes.data_as(L.p_f64), cells.shape[0],
-                                                    cells.ctypes.data_as(L.p_i64), own.ctypes.data_as(L.p_i32),
-                                                    rank, nranks, ctypes.byref(h)))
+        if cut_owner is None:
+            L.check(self._lib.hmg_grid_create_partition(ctx.h if ctx else None, base.dim, levels, nodes.shape[0],
+                                                        nodes.ctypes.data_as(L.p_f64), cells.shape[0],
+                                                        cells.ctypes.data_as(L.p_i64), own.ctypes.data_as(L.p_i32),
+                                                        rank, nranks, ctypes.byref(h)))
+        else:
+            cown = np.ascontiguousarray(cut_owner, dtype=np.int32)
+            assert cown.shape == own.shape
+            L.check(self._lib.hmg_grid_create_partition_rehearsal(
+                ctx.h if ctx else None, base.dim, levels, nodes.shape[0], nodes.ctypes.data_as(L.p_f64), cells.shape[0],
+                cells.ctypes.data_as(L.p_i64), own.ctypes.data_as(L.p_i32), cown.ctypes.data_as(L.p_i32), rank, nranks,
+                ctypes.byref(h)))
         self.h = h
         self.local_cells = self.table_i32("part_cells").astype(np.int64)     # global ids, ascending
         self.local_nodes = self.table_i32("part_nodes").astype(np.int64)
@@ -87,10 +97,14 @@ class Exchange:
     backend "torch": callbacks into torch.distributed (any backend that reduces device tensors, e.g. gloo for
     single-GPU rehearsals); the collectives are issued on the CONTEXT's stream, whatever torch's current stream is."""
 
-    def __init__(self, ctx: api.Context, grid: PartitionedGrid, group=None, backend: str | None = None):
+    def __init__(self, ctx: api.Context, grid: PartitionedGrid, group=None, backend: str | None = None,
+                 comm_ranks: tuple | None = None):
+        """comm_ranks = (rank, nranks) of the communicator when it differs from the grid's partition (rehearsal of one
+        rank's share of a larger partition, context option comm_rehearsal)."""
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.ctx = dist, group, ctx
+        crank, cn = comm_ranks if comm_ranks is not None else (grid.rank, grid.nranks)
         if backend is None:
             backend = "rccl" if dist.is_initialized() and dist.get_backend(group) == "nccl" else "torch"
         self.backend = backend
@@ -101,11 +115,13 @@ class Exchange:
         lib = L.load()
         if backend == "rccl":
             if not getattr(ctx, "_comm_ready", False):
-                uid = [api.Context.comm_unique_id() if grid.rank == 0 else None]
-                if grid.nranks > 1:
+                uid = [api.Context.comm_unique_id() if crank == 0 else None]
+                if cn > 1:
                     dist.broadcast_object_list(uid, src=0, group=group)
-                ctx.comm_init(grid.nranks, grid.rank, uid[0])
+                ctx.comm_init(cn, crank, uid[0])
                 ctx._comm_ready = True
+            if comm_ranks is not None and (crank, cn) != (grid.rank, grid.nranks):
+                ctx.set_option("comm_rehearsal", 1)
             L.check(lib.hmg_grid_use_comm(grid.h))
             grid._exchange = self
             return
@@ -240,9 +256,21 @@ class PartitionedProblem:
 
 
 def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int, seed: int = 0, values=(1.0, 9.0),
-                             lam: float = 1.0, group=None, backend=None):
-    """Weak-scaling checkerboard: a brick of `world` blocks of width^3 unit cubes, one block per rank."""
-    blocks = block_shape(world, 3)
+                             lam: float = 1.0, group=None, backend=None, synthetic_cut: bool = False,
+                             rehearse_world: int | None = None):
+    """Weak-scaling checkerboard: a brick of `world` blocks of width^3 unit cubes, one block per rank.
+
+    Two single-GPU rehearsals of the partitioned code path (world = 1, a 1-rank communicator):
+      synthetic_cut      the one block is cut by its three mid-planes (cut_owner = octant of a cell): every cut entity
+                         has all its copies on this rank, the sum over ranks is the identity, the results equal the
+                         unpartitioned grid's bit for bit -- cut-first cell lists, pack / unpack, events and the
+                         all-reduce of an 8-rank partition run at full size;
+      rehearse_world=N   this process holds rank 0's block of the N-rank brick (config 4: N = 8, 64^3 cubes) and its cut
+                         tables, replicated level-1 system included; the neighbours' contributions are missing from the
+                         sums, so the numbers mean nothing, but per-rank work, message sizes and stream choreography are
+                         those of the real run."""
+    layout = rehearse_world if rehearse_world else world
+    blocks = block_shape(layout, 3)
     shape = tuple(width * b for b in blocks)
     origin = tuple(-s / 2.0 for s in shape)
     base = driver.checkerboard_mesh(api.Tet64, shape, origin=origin, transposed_lookup=False)
@@ -250,8 +278,16 @@ def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int
     sgrid = np.where(rng.random(shape + (3,)) < 0.5, values[0], values[1])
     cond = driver.conductivity_per_element(base, sgrid, tuple(1.0 - o for o in origin))
     owner = block_owner(base, blocks, width, origin)
-    grid = PartitionedGrid(ctx, base, levels, owner, rank, world)
-    ex = Exchange(ctx, grid, group, backend)
+    cut_owner = None
+    if synthetic_cut:
+        assert layout == 1 and width % 2 == 0, "the synthetic cut splits one block of even width at its mid-planes"
+        cut_owner = block_owner(base, (2, 2, 2), width // 2, origin)
+    if rehearse_world:
+        grid = PartitionedGrid(ctx, base, levels, owner, rank, rehearse_world)
+        ex = Exchange(ctx, grid, group, backend, comm_ranks=(rank, world))
+    else:
+        grid = PartitionedGrid(ctx, base, levels, owner, rank, world, cut_owner=cut_owner)
+        ex = Exchange(ctx, grid, group, backend)
     op = api.L2PlusDivAGrad(grid, lam, cond)
     p = PartitionedProblem()
     p.base, p.cond, p.implicit, p.op, p.exchange = grid.base, cond, grid, op, ex

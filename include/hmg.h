@@ -225,6 +225,16 @@ int hmg_comm_sum_host(hmg_ctx *ctx, double *vals, int count);
  * hmg_grid_set_cut is called internally; the host only supplies hmg_grid_set_exchange. */
 int hmg_grid_create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
                               const int64_t *cells, const int32_t *owner, int rank, int nranks, hmg_grid **out);
+/* Rehearsal of a larger partition on fewer GPUs (measurement / test aid, not a production entry point).
+ * cut_owner[c] decides which entities count as cut (their copies' cells differ in cut_owner) while owner[] still decides
+ * which cells are local: owner = 0 everywhere, cut_owner = the octant of a cell and a 1-rank communicator walk the
+ * cut-first cell lists, pack / unpack kernels, events and the all-reduce of an 8-rank partition with every copy held
+ * locally -- results equal the unpartitioned grid's bit for bit.  cut_owner = NULL: as hmg_grid_create_partition.
+ * Context option "comm_rehearsal" = 1 lets a grid that holds rank r's share of an N-rank partition use a communicator
+ * of another size (timing only: the neighbours' contributions are missing from the sums). */
+int hmg_grid_create_partition_rehearsal(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords,
+                                        int64_t ncells, const int64_t *cells, const int32_t *owner, const int32_t *cut_owner,
+                                        int rank, int nranks, hmg_grid **out);
 
 /* ---- host-side problem synthesis (threaded; HMG_SETUP_THREADS, default: all cores up to 16) -------------------------
  * hypercube(ElT, n; origin) + order_nodes_and_elements_by_magnitude (src/tet/generate_grid.jl:6-45,

@@ -168,3 +168,47 @@ def test_partitioned_interface_sum_matches_serial(world, dim, shape, levels):
         p.join(timeout=60)
     for rank, msg in sorted(res):
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_synthetic_cut_tables_match_the_eight_rank_partition():
+    """Rehearsal partition (hmg_grid_create_partition_rehearsal): one rank holds every cell, cut_owner = the octant of a
+    cell.  The cut entities are those of the real 8-rank partition (same global counts, same ids); every copy is local;
+    the cut face pairs lead the pair list; edge / node groups and cells are split cut-first as in a real partition."""
+    sys.path.insert(0, ROOT)
+    import homogenization_jl_amd as hmg
+    from homogenization_jl_amd import dist as hdist, driver
+    w, L = 4, 3
+    base = driver.checkerboard_mesh(hmg.Tet64, (w, w, w), origin=(-w / 2.0,) * 3, transposed_lookup=False)
+    octant = hdist.block_owner(base, (2, 2, 2), w // 2, (-w / 2.0,) * 3)
+    zero = np.zeros_like(octant)
+    syn = hdist.PartitionedGrid(None, base, L, zero, 0, 1, cut_owner=octant)
+    cs = syn.table_i32("cut_counts")
+    assert syn.local_cells.size == base.elements.shape[0]
+    real = [hdist.PartitionedGrid(None, base, L, octant, r, 8) for r in range(8)]
+    cr = [g.table_i32("cut_counts") for g in real]
+    for k in range(3):
+        assert all(c[k] == cs[k] for c in cr)                      # global cut counts agree
+        assert cs[3 + k] == sum(c[3 + k] for c in cr)              # the one rank holds every copy
+    # a real partition has no cut face with two local copies; the rehearsal has all of them, leading the pair list
+    assert all(c[6] == 0 for c in cr) and cs[6] == cs[0]
+    fp = syn.table_i32("face_pairs").reshape(-1, 3)
+    cut_faces = set(syn.table_i32("cut_ent_faces").tolist())
+    lead = {int(a) * 8 + (int(lf) & 15) for a, b, lf in fp[:cs[6]]} | {int(b) * 8 + (int(lf) >> 4) for a, b, lf in fp[:cs[6]]}
+    assert lead == cut_faces
+    rest = {int(a) * 8 + (int(lf) & 15) for a, b, lf in fp[cs[6]:]}
+    assert not (rest & cut_faces)
+    # same ids for the same entity: the copies (global cell, local entity) behind every cut id agree with the real ranks'
+    for kind in ("faces", "edges", "nodes"):
+        want = {}
+        for g in real:
+            gid, ent = g.table_i32("cut_gid_" + kind), g.table_i32("cut_ent_" + kind)
+            for i, e in zip(gid, ent):
+                want.setdefault(int(i), set()).add((int(g.local_cells[e >> 3]), int(e & 7)))
+        got = {}
+        for i, e in zip(syn.table_i32("cut_gid_" + kind), syn.table_i32("cut_ent_" + kind)):
+            got.setdefault(int(i), set()).add((int(syn.local_cells[e >> 3]), int(e & 7)))
+        assert got == want
+    assert cs[9] + cs[10] == base.elements.shape[0] and cs[9] > 0 and cs[10] > 0   # cut cells first, inner cells after
+    # without cut_owner a one-rank partition has no cut at all
+    plain = hdist.PartitionedGrid(None, base, L, zero, 0, 1)
+    assert not plain.table_i32("cut_counts").any() or plain.table_i32("cut_counts")[10] == base.elements.shape[0]

@@ -202,6 +202,46 @@ def test_in_library_rccl_communicator_single_rank(oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("w,L", [(4, 4), (2, 6)])
+def test_synthetic_cut_rehearsal_is_bit_identical(w, L):
+    """The partitioned code path at work on ONE rank (src/implicit_fine_grid.jl:209-328 called at
+    src/multigrid.jl:51,61,75): the block is cut at its three mid-planes (cut_owner = octant), a 1-rank RCCL communicator
+    does the sums over ranks (the identity).  Cut-first cell lists, cut groups / cut face pairs summed before the pack,
+    k_cut_pack / unpack, ev_packed / ev_summed and ncclAllReduce on the second stream all run; x and r after two V-cycles
+    equal the unpartitioned grid's bit for bit, with the overlap on and off."""
+    import homogenization_jl_amd as hmg
+    from homogenization_jl_amd import dist as hdist
+    for overlap in (True, False):
+        ctx = hmg.Context(0)
+        try:
+            prob = hdist.partitioned_checkerboard(ctx, w, L, 1, 0, seed=3, backend="rccl", synthetic_cut=True)
+            g = prob.implicit
+            prob.exchange.set_overlap(g, overlap)
+            counts = g.table_i32("cut_counts")
+            assert counts[0] > 0 and counts[1] > 0 and counts[2] > 0 and counts[6] == counts[0] and counts[9] > 0
+            g1 = hmg.ImplicitFineGrid(ctx, prob.global_base, L)
+            op1 = hmg.L2PlusDivAGrad(g1, 1.0, prob.cond)
+            sts_p = [hmg.LevelState(g, i + 1) for i in range(L)]
+            sts_s = [hmg.LevelState(g1, i + 1) for i in range(L)]
+            for st, gg in ((sts_p, g), (sts_s, g1)):
+                st[-1].x.rand(5); st[-1].b.rand(6)
+                hmg.broadcast_interfaces(st[-1].x, gg, L)
+                hmg.apply_constraint(st[-1].x, L, gg)
+            np.testing.assert_array_equal(sts_p[-1].x.to_host(), sts_s[-1].x.to_host())
+            bl_p, bl_s = prob.base_level(), hmg.BaseLevel(g1)
+            calls0, _ = prob.exchange.stats()
+            for _ in range(2):
+                hmg.vcycle(g, bl_p, [prob.op] * L, sts_p, L, 3)
+                hmg.vcycle(g1, bl_s, [op1] * L, sts_s, L, 3)
+            np.testing.assert_array_equal(sts_p[-1].x.to_host(), sts_s[-1].x.to_host())
+            np.testing.assert_array_equal(sts_p[-1].r.to_host(), sts_s[-1].r.to_host())
+            assert hmg.norm_unique(sts_p[-1].r) == hmg.norm_unique(sts_s[-1].r)
+            calls, doubles = prob.exchange.stats()
+            assert calls > calls0 and doubles >= counts[0] * g.nf(L) // 100
+        finally:
+            ctx.close()
+
+
 def test_unsupported_world_size_raises_everywhere():
     """3, 6, 16 ranks (or 8 in 2D) would leave ranks without cells: refused before any collective."""
     import homogenization_jl_amd as hmg
