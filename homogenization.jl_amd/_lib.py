@@ -74,6 +74,7 @@ SIGNATURES = {
     "hmg_coarse_setup": (c_int, [vp]),
     "hmg_coarse_solve": (c_int, [vp, vp, vp]),
     "hmg_coarse_last_iterations": (c_int, [vp]),
+    "hmg_coarse_misses": (c_i64, [vp]),
     "hmg_vcycle": (c_int, [vp, c_int, c_int, c_int, pp]),
     "hmg_vcycle_down": (c_int, [vp, c_int, c_int, pp]),
     "hmg_vcycle_up": (c_int, [vp, c_int, c_int, pp]),

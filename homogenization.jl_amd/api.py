@@ -477,7 +477,16 @@ class BaseLevel:
         implicit.coarse_setup()
 
     def last_iterations(self):
-        return int(L.load().hmg_coarse_last_iterations(self.implicit.h))
+        """Iterations of the last level-1 solve (waits for it).  Raises if that solve did not converge."""
+        n = int(L.load().hmg_coarse_last_iterations(self.implicit.h))
+        if n < 0:
+            raise L.HmgError(L.load().hmg_last_error().decode())
+        return n
+
+    def misses(self):
+        """Budgeted level-1 solves that ran out of iterations so far (each was reported as an error, or dropped with
+        the matrix it belonged to)."""
+        return int(L.load().hmg_coarse_misses(self.implicit.h))
 
 
 def vcycle(implicit: ImplicitFineGrid, base: BaseLevel, ops, levels, k: int, steps: int = 2, steps_coarse: int = 2):

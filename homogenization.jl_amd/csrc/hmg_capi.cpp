@@ -75,6 +75,8 @@ struct LevelBufs {
     DevBuf<double> rtab;   // restriction weights in class-table layout (slab levels)
     int nslab = 0, slab_lds_nodes = 0;
     DevBuf<uint32_t> pos32, pos32w, sweep32, par32, blk_word;
+    DevBuf<uint64_t> par64;
+    DevBuf<uint16_t> clpos;
     DevBuf<uint16_t> blk_slot;
     int nblk = 0, blk_R = 0;
     DevBuf<double> ctab;
@@ -114,7 +116,8 @@ struct hmg_ctx {
     bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
-    bool prolong_gather = true;  // folded prolongation, level 6: parents gathered from global memory instead of an LDS copy of the coarse column
+    bool prolong_in_image = true;  // folded prolongation, level 6: the coarse column is staged at the even nodes of the lattice image
+                                   // instead of in LDS of its own behind it (three workgroups per CU stay resident)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -139,6 +142,9 @@ struct hmg_ctx {
     // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
     // the work per rank, the message sizes and the stream choreography are the real ones, the numbers are not)
     bool comm_rehearsal = false;
+    // grids of this context whose last budgeted level-1 solve still has its probe in flight: judged at the next call that
+    // synchronises the stream anyway (norms, dot products, integrals, hmg_ctx_sync, downloads)
+    std::vector<struct hmg_grid *> probe_grids;
 };
 
 namespace {
@@ -209,6 +215,7 @@ struct CoarseProbe {
     hipEvent_t ev = nullptr;
     bool pending = false;
     int budget = 0;                 // iterations launched by the solve the probe belongs to
+    int generation = 0;             // the level-1 matrix (hmg_grid::coarse_generation) that solve used
 };
 
 }  // namespace
@@ -240,6 +247,9 @@ struct hmg_grid {
     DevBuf<double> c_val, c_diag, c_b, c_x, c_r, c_z, c_p, c_q, c_u;
     int coarse_last_it = 0;
     int coarse_budget = 0;                       // iterations a solve enqueues blindly (0: not known yet)
+    int coarse_generation = 0;                   // counts the level-1 matrices assembled for this grid
+    int64_t coarse_misses = 0;                   // budgeted solves that ran out of iterations (each one was reported or, with a
+                                                 // new matrix in between, only counted)
     std::unique_ptr<CoarseProbe> probe{new CoarseProbe};
     // multi-GPU
     std::unique_ptr<Partition> part;
@@ -645,6 +655,31 @@ static void upload_levels(hmg_grid *g)
                 B.par32.upload(pp, s);
             }
             B.par_b.upload(T.par_b, s);
+            if (l > 0 && T.dim == 3 && B.nblk > 0 && T.nf <= 0xffff) {
+                // folded prolongation, coarse column staged in the image itself (k_apply<.., CG>): coarse slot c = lattice
+                // node (ci,cj,ck) of the coarser level sits at the fine lattice node (2ci,2cj,2ck)
+                const LevelTables &C = g->lt[l - 1];
+                const int m = T.m;
+                std::vector<int32_t> lat((size_t)(m + 1) * (m + 1) * (m + 1), -1);
+                auto at = [&](int i, int j, int k) -> int32_t & { return lat[((size_t)k * (m + 1) + j) * (m + 1) + i]; };
+                for (int q = 0; q < T.nf; ++q)
+                    at(T.slot_ijk[3 * q], T.slot_ijk[3 * q + 1], T.slot_ijk[3 * q + 2]) = (int32_t)(T.meta[q] & 0xffffu);
+                std::vector<uint16_t> cl((size_t)C.nf);
+                for (int c = 0; c < C.nf; ++c) {
+                    const int32_t Lp = at(2 * C.slot_ijk[3 * c], 2 * C.slot_ijk[3 * c + 1], 2 * C.slot_ijk[3 * c + 2]);
+                    if (Lp < 0) throw std::runtime_error("prolongation tables: coarse node without a fine lattice node");
+                    cl[c] = (uint16_t)Lp;
+                }
+                std::vector<uint64_t> p64((size_t)T.nf);
+                for (int q = 0; q < T.nf; ++q) {
+                    const uint64_t a = cl[(size_t)T.par_a[q]], b = cl[(size_t)T.par_b[q]], self = T.meta[q] & 0xffffu;
+                    // (an identity row is its own parent: the coarse value sits where the slot's own value will go)
+                    if (T.par_a[q] == T.par_b[q] && a != self) throw std::runtime_error("prolongation tables: identity row off its node");
+                    p64[q] = a | (b << 16) | (self << 32);
+                }
+                B.clpos.upload(cl, s);
+                B.par64.upload(p64, s);
+            }
             B.rptr.upload(T.rptr, s);
             B.ridx.upload(T.ridx, s);
             B.dphi.upload(T.dphi, s);
@@ -686,6 +721,8 @@ static void upload_levels(hmg_grid *g)
         D.par_a = B.par_a.p;
         D.par32 = B.par32.p;
         D.par_b = B.par_b.p;
+        D.par64 = B.par64.p;
+        D.clpos = B.clpos.p;
         D.rptr = B.rptr.p;
         D.ridx = B.ridx.p;
         D.dphi = B.dphi.p;
@@ -938,7 +975,7 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             a.ldc = lev(g, level - 1).ld;
             a.xout = x->d;
             // (cells that fill a third of the LDS: no room for the coarse column next to three resident images)
-            if (g->ctx->prolong_gather && apply_lds_bytes(lv) > 48 * 1024) a.flags |= 64;
+            if (g->ctx->prolong_in_image && apply_lds_bytes(lv) > 48 * 1024) a.flags |= 64;
             apply_then_sum(g, lv, a, true, -1, -1);
         } else {
             apply_then_sum(g, lv, a, false, -1, -1);
@@ -1043,6 +1080,8 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
     return none;
 }
 
+void coarse_probe_drop(hmg_grid *g);
+
 void coarse_setup(hmg_grid *g)
 {
     need(g->has_op, "hmg_grid_set_operator must be called first");
@@ -1070,7 +1109,12 @@ void coarse_setup(hmg_grid *g)
     g->cd.diag = g->c_diag.p;
     g->cd.interior = g->c_interior.p;
     g->coarse_ready = true;
-    g->coarse_budget = 0;                          // new matrix: the first solve counts its iterations again
+    // New matrix: the first solve counts its iterations again.  A probe the previous matrix's last solve left behind is
+    // waited for and dropped here -- judged by coarse_pcg() it would put the old matrix's count back into the budget
+    // (max), and the first solve on the new, possibly harder, system would be enqueued blindly with it.
+    coarse_probe_drop(g);
+    g->coarse_generation += 1;
+    g->coarse_budget = 0;
 }
 
 void coarse_probe_wait(hmg_grid *g);
@@ -1114,6 +1158,8 @@ void coarse_pcg(hmg_grid *g)
         HIPCHK(hipMemcpyAsync(pr.h + 3, L.scal + S_C2, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(pr.ev, c->stream));
         pr.pending = true;
+        pr.generation = g->coarse_generation;
+        if (std::find(c->probe_grids.begin(), c->probe_grids.end(), g) == c->probe_grids.end()) c->probe_grids.push_back(g);
     };
     if (g->coarse_budget > 0) {
         iterate(g->coarse_budget);
@@ -1140,23 +1186,59 @@ void coarse_pcg(hmg_grid *g)
     g->coarse_budget = std::min(c->coarse_maxit, g->coarse_last_it + g->coarse_last_it / 2 + 16);
 }
 
-// Blocks until the probe of the last budgeted solve has landed and judges it.
+static void probe_unlist(hmg_grid *g)
+{
+    if (!g->ctx) return;
+    auto &v = g->ctx->probe_grids;
+    v.erase(std::remove(v.begin(), v.end(), g), v.end());
+}
+
+// Blocks until the probe of the last budgeted solve has landed and judges it.  A solve that ran out of its budget is an
+// error (its unconverged x has already been prolonged): the budget is reset, so the caller may simply repeat the V-cycle
+// -- the next solve counts its iterations the slow way.
 void coarse_probe_wait(hmg_grid *g)
 {
     if (!g->probe || !g->probe->pending) return;
     CoarseProbe &pr = *g->probe;
     HIPCHK(hipEventSynchronize(pr.ev));
     pr.pending = false;
+    probe_unlist(g);
+    if (pr.generation != g->coarse_generation) return;      // (a solve on a matrix that is gone: coarse_probe_drop counts those)
     const double done = pr.h[0], rr = pr.h[2], bb = pr.h[3];
     g->coarse_last_it = (int)pr.h[1];
     if (!std::isfinite(rr) || !std::isfinite(bb)) throw std::runtime_error("coarse PCG diverged (non-finite residual)");
     if (done == 0.0 && bb > 0.0) {
         g->coarse_budget = 0;                      // next solve: find the count the slow way again
-        throw std::runtime_error("coarse PCG: the previous level-1 solve did not reach coarse_rtol within the " +
-                                 std::to_string(pr.budget) + " iterations enqueued for it");
+        g->coarse_misses += 1;
+        throw std::runtime_error("coarse PCG: the last level-1 solve did not reach coarse_rtol within the " +
+                                 std::to_string(pr.budget) + " iterations enqueued for it (relative residual " +
+                                 std::to_string(std::sqrt(rr / bb)) + "); the V-cycle that used it is inexact -- repeat it, "
+                                 "the next solve counts its iterations again");
     }
     g->coarse_budget = std::max(g->coarse_budget,
                                 std::min(g->ctx->coarse_maxit, g->coarse_last_it + g->coarse_last_it / 2 + 16));
+}
+
+// A new level-1 matrix is about to replace the one the pending probe belongs to: wait for it, count a miss, drop it.
+void coarse_probe_drop(hmg_grid *g)
+{
+    if (!g->probe || !g->probe->pending) return;
+    CoarseProbe &pr = *g->probe;
+    (void)hipEventSynchronize(pr.ev);
+    pr.pending = false;
+    probe_unlist(g);
+    if (pr.h[0] == 0.0 && pr.h[3] > 0.0) g->coarse_misses += 1;
+}
+
+// Called wherever the API has just synchronised the context's stream: probes that have landed by then are judged at once,
+// so an unconverged budgeted solve is reported by the call that follows its V-cycle (the driver's integrals / residual
+// norm), not by the next V-cycle -- and the last V-cycle of a run is judged as well.
+void judge_probes(hmg_ctx *c)
+{
+    while (!c->probe_grids.empty()) {
+        hmg_grid *g = c->probe_grids.back();
+        coarse_probe_wait(g);                      // (removes g from the list, may throw)
+    }
 }
 
 void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
@@ -1437,6 +1519,7 @@ static void grid_unref(hmg_grid *grid)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
     }
+    probe_unlist(grid);
     if (grid->probe && grid->probe->h) (void)hipHostFree(grid->probe->h);
     if (grid->probe && grid->probe->ev) (void)hipEventDestroy(grid->probe->ev);
     delete grid;
@@ -1444,6 +1527,7 @@ static void grid_unref(hmg_grid *grid)
 }
 
 static double read_scalar(hmg_ctx *c, int slot);
+namespace { void judge_probes(hmg_ctx *c); }
 
 extern "C" {
 
@@ -1507,6 +1591,7 @@ int hmg_ctx_sync(hmg_ctx *ctx)
     HMG_TRY
     need(ctx != nullptr, "null ctx");
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    judge_probes(ctx);
     HMG_END
 }
 
@@ -1552,8 +1637,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->fold_faces = value != 0;
     else if (n == "lean_post")
         ctx->lean_post = value != 0;
-    else if (n == "prolong_gather")
-        ctx->prolong_gather = value != 0;
+    else if (n == "prolong_in_image" || n == "prolong_gather")   // (prolong_gather: the option's name in round 2)
+        ctx->prolong_in_image = value != 0;
     else if (n == "comm_rehearsal")
         ctx->comm_rehearsal = value != 0;
     else if (n == "vec_pool") {
@@ -2048,6 +2133,7 @@ static double read_scalar(hmg_ctx *c, int slot)
     double h = 0.0;
     HIPCHK(hipMemcpyAsync(&h, c->L.scal + slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    judge_probes(c);
     return h;
 }
 
@@ -2321,6 +2407,8 @@ int hmg_coarse_last_iterations(const hmg_grid *g)
     }
     return g->coarse_last_it;
 }
+
+int64_t hmg_coarse_misses(const hmg_grid *g) { return g ? g->coarse_misses : -1; }
 
 int hmg_vcycle(hmg_grid *g, int top_level, int steps, int steps_coarse, hmg_vec **states)
 {

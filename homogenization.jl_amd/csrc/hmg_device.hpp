@@ -35,6 +35,9 @@ struct LevelDev {
     const int32_t *hier2slot;      // [nf]
     const int32_t *par_a, *par_b;  // [nf]     (level > 1)
     const uint32_t *par32;         // [nf]     par_a | par_b << 16 (coarse storage slots; level > 1)
+    // folded prolongation with the coarse column staged at the EVEN nodes of the lattice image (3D levels with blocked tables):
+    const uint64_t *par64;         // [nf]     LDS lattice position of parent a | of parent b << 16 | of the slot itself << 32
+    const uint16_t *clpos;         // [nf_coarse] LDS lattice position (fine lattice, node (2i,2j,2k)) of every coarse slot
     const int32_t *rptr, *ridx;    // [nf_coarse+1], [..] (level > 1)
     const double *dphi;            // [3*nf]
 };

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 #define HMG_STAMP(i)
 #endif
 
-// WD: instantiation for the driver integrals (flags bit 3); CG: the folded prolongation gathers from global memory (flags bit 6)
+// WD: instantiation for the driver integrals (flags bit 3); CG: the folded prolongation stages the coarse column at the even nodes
+// of the lattice image itself (flags bit 6; cells that fill a third of the LDS have no room for it behind the image)
 template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false, bool CG = false>
 __global__ void __launch_bounds__(NT, NT >= 640 ? 8 : RB && NT == 512 ? 6 : 1)   // 2 x 1024 threads per CU need <= 64 VGPRs, 3 x 512: 80
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
@@ -199,9 +200,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // src/interpolation.jl:64-74: identity rows += 1.0 c[a], midpoints += 0.5 c[a], += 0.5 c[b] in the CSC
         // column order), from the cell's coarse column staged in LDS behind the lattice image
         const double *ccol = FUSED && a.xcoarse ? a.xcoarse + cell * a.ldc : nullptr;
-        // (CG, flags bit 6: the coarse column is not staged -- every slot gathers its one or two parents from global memory,
-        //  L1/L2 hits after the first touch of the 7.6 KB column; the LDS then holds nothing but the image, so that the
-        //  512-thread instantiation keeps three workgroups per CU)
+        // (CG, flags bit 6: no room behind the image -- see the in-image path below)
         constexpr bool cgather = FUSED && CG;
         double *cs = xs + nf + lv.lds_g1;
         double cval = 0.0;
@@ -211,15 +210,68 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
         auto prolong = [&](double v, uint32_t w) {
             const uint32_t pa = w & 0xffffu, pb = w >> 16;
-            if (cgather) {
-                if (pa == pb) return v + ccol[pa];
-                v += 0.5 * ccol[pa];
-                return v + 0.5 * ccol[pb];
-            }
             if (pa == pb) return v + cs[pa];
             v += 0.5 * cs[pa];
             return v + 0.5 * cs[pb];
         };
+        // CG: the coarse column goes to the EVEN nodes of the lattice image (coarse node (i,j,k) = fine node (2i,2j,2k)),
+        // every thread combines its slots' parents from there into registers, and only then -- behind a second barrier --
+        // the image receives the fine values: no LDS beyond the image (three workgroups per CU stay resident), no gathers
+        // from global memory (round 2: two dependent L1/L2 gathers per slot made this the slowest launch of the V-cycle,
+        // 4.2 TB/s), the whole column in one batch of loads like the light passes.  Same roundings as the staged form.
+        if (cgather && ccol) {
+            constexpr int NC = 2;                                   // coarse slots per thread (host: nf_coarse <= NC * NT)
+            double cv2[NC];
+            int cl2[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = tid + q * NT;
+                if (c < lv.nf_coarse) {
+                    cv2[q] = ccol[c];
+                    cl2[q] = lv.clpos[c];
+                }
+            }
+            double xv[SPT];
+            uint64_t pw[SPT];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                if (t < nf) {
+                    xv[q] = xc[t];
+                    pw[q] = lv.par64[t];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (tid + q * NT < lv.nf_coarse) xs[cl2[q]] = cv2[q];
+            __syncthreads();                                        // coarse values in place
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                if (t < nf) {
+                    const uint32_t pa = (uint32_t)pw[q] & 0xffffu, pb = ((uint32_t)pw[q] >> 16) & 0xffffu;
+                    double v = xv[q];
+                    if (pa == pb)
+                        v = v + lds_ld(xs + pa);
+                    else {
+                        v += 0.5 * lds_ld(xs + pa);
+                        v = v + 0.5 * lds_ld(xs + pb);
+                    }
+                    xv[q] = v;
+                }
+            }
+            __syncthreads();                                        // every parent read: the image may take the fine values
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) {
+                const int t = tid + q * NT;
+                if (t < nf) {
+                    const double v = xv[q];
+                    if (xoc) xoc[t] = v;
+                    rr += v * v;
+                    xs[(int)(pw[q] >> 32)] = v;
+                }
+            }
+        }
         // A fused pass that reads nothing but its own column (CG step 0 with r itself as p: no x2 / xacc / x3 / coarse
         // column) takes the whole column in ONE batch like the plain apply -- one memory round trip instead of two.
         const bool light = FUSED && NT >= 512 && !x2c && !xac && !x3c && !ccol;   // (level 5, 256 threads: the extra path costs a resident workgroup)
@@ -271,7 +323,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             }
         }
         constexpr int HB = FUSED ? (SPT + 1) / 2 : SPT;
-        if (!light && !light2) {
+        if (!light && !light2 && !(cgather && ccol)) {
 #pragma unroll
         for (int q0 = 0; q0 < SPT; q0 += HB) {
             double xv[HB], x2v[HB], xav[HB];
@@ -285,7 +337,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     x2v[q] = x2c ? x2c[t] : 0.0;
                     xav[q] = xac ? xac[t] : x3c ? x3c[t] : 0.0;
                     lp[q] = lv.lpos[t];
-                    if (FUSED) pw[q] = ccol ? lv.par32[t] : 0u;
+                    if (FUSED && !cgather) pw[q] = ccol ? lv.par32[t] : 0u;
                 }
             }
             if (EARLY && q0 == 0) finish_tables();          // (the rows were requested before this batch's loads)
@@ -299,7 +351,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 if (q0 + q < SPT && t < nf) {
                     double v = xv[q];
                     if (FUSED) {
-                        if (ccol) v = prolong(v, pw[q]);
+                        if (!cgather && ccol) v = prolong(v, pw[q]);
                         if (xac) xac[t] = xav[q] + ax * x2v[q];
                         if (x3c) {
                             const double t1 = v + ax * x2v[q];
@@ -319,7 +371,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             double v = xc[t];
             if (FUSED) {
                 const double pv = x2c ? x2c[t] : 0.0;
-                if (ccol) v = prolong(v, lv.par32[t]);
+                if (!cgather && ccol) v = prolong(v, lv.par32[t]);
                 if (xac) xac[t] = xac[t] + ax * pv;
                 if (x3c) {
                     const double t1 = v + ax * pv;
@@ -774,7 +826,10 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     } else if (DIM == 3 && lv.blk_R == 6 && lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked) {
         if constexpr (!WD) {
             if (L.apply_wg512 && lv.nfi <= 512) {
-                if (FUSED && DIM == 3 && a.xcoarse && (a.flags & 64))   // (own instantiation: the gather costs the others registers)
+                // (own instantiation: the in-image staging of the coarse column costs the others registers; it handles the
+                //  residual of the coarse-grid correction only -- no pending CG updates -- and one batch of 13 slots)
+                if (FUSED && DIM == 3 && a.xcoarse && (a.flags & 64) && lv.par64 && lv.clpos && !a.x2 && !a.xacc && !a.x3 &&
+                    lv.nf <= 13 * 512 && lv.nf_coarse <= 2 * 512)
                     launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0, false, FUSED && DIM == 3>(L, lv, mesh, a,
                                                                                                       apply_lds_bytes_rb(lv));
                 else

@@ -58,9 +58,9 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * p-update and, below the top level, everything of the last CG step but x += alpha p; x of every level and r of the
  * top level are unchanged bit for bit, p / Ap (and r below the top level) are scratch on return, as they are for the
  * reference's own callers: the next smoothing_steps! overwrites them before reading, src/multigrid.jl:46-50;
- * 0 = they hold what the reference leaves), "prolong_gather" (1 = default: on level 6 the folded prolongation gathers
- * the parents from global memory instead of staging the coarse column in LDS, which would cost the third resident
- * workgroup), "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
+ * 0 = they hold what the reference leaves), "prolong_in_image" (1 = default: on level 6 the folded prolongation stages the
+ * coarse column at the even nodes of the LDS lattice image itself instead of in LDS of its own behind it, which would cost
+ * the third resident workgroup; "prolong_gather", the option's round-2 name, is still accepted), "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
  * hmg_vec_create of the same size -- re-allocating freed device memory costs ~35 ms per GB here; 0 = free at once and
  * release what is held; hmg_ctx_destroy releases it too), "coarse_maxit", "coarse_check",
  * "time_apply"; "coarse_rtol" via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
@@ -158,7 +158,16 @@ int hmg_smooth(hmg_grid *grid, int level, int steps, hmg_vec *x, hmg_vec *b, hmg
 int hmg_coarse_setup(hmg_grid *grid);
 /* level-1 branch of vcycle!                                  (src/multigrid.jl:74-93) */
 int hmg_coarse_solve(hmg_grid *grid, hmg_vec *b1, hmg_vec *x1);
+/* Iterations of the last level-1 solve; blocks until its probe has landed.  -1 (hmg_last_error set): that solve did not
+ * reach coarse_rtol.  How a solve is policed: the first solve on a new matrix (operator, lambda or domain changed) looks at
+ * its residual every "coarse_check" iterations and fails with an error after "coarse_maxit"; later solves enqueue
+ * 1.5 x the largest count seen + 16 iterations without a host round trip and leave a probe behind, which is judged by the
+ * next call that synchronises the stream anyway (hmg_vec_norm_unique, hmg_vec_dot, hmg_integrate, hmg_ctx_sync, this
+ * function) or by the next solve: an unconverged solve is an ERROR of that call (the V-cycle that used it was inexact),
+ * the budget is dropped, and repeating the V-cycle solves the slow, checked way.  The reference's CHOLMOD solve
+ * (src/multigrid.jl:84) cannot fail this way; the error keeps that contract visible. */
 int hmg_coarse_last_iterations(const hmg_grid *grid);
+int64_t hmg_coarse_misses(const hmg_grid *grid);   /* budgeted solves that ran out of iterations so far */
 /* vcycle!(implicit, base, ops, levels, k, steps); coarser levels use steps_coarse (the reference
  * does not forward `steps`, src/multigrid.jl:109, so pass 2 for parity).
  * states: 5*nlevels handles ordered level-major as x,b,r,p,Ap of level 1, then level 2, ... */

@@ -185,7 +185,7 @@ def test_l6_smoothing_steps(case6, steps):
 
 
 DEFAULT_WG512 = 1      # hmg_ctx_create's default (see hmg_ctx_set_option in include/hmg.h)
-OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead", "lean_post", "prolong_gather")
+OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead", "lean_post", "prolong_in_image")
 
 
 @pytest.mark.parametrize("plain", [0, 1])
@@ -237,7 +237,7 @@ def test_l6_vcycle_up_leg(case6, ctx, plain):
     for o in OPTS:
         ctx.set_option(o, 0 if plain == 1 else 1)
     if plain == 2:                                  # every fold, the coarse column staged in LDS (two workgroups per CU)
-        ctx.set_option("prolong_gather", 0)
+        ctx.set_option("prolong_in_image", 0)
     try:
         states = [None] * 6
         states[4], states[5] = hmg.LevelState(c.g, 5), hmg.LevelState(c.g, 6)
