@@ -177,6 +177,12 @@ def main():
     dist = None
     if world > 1 or force_part:
         import torch.distributed as dist
+        if world == 1 and "RANK" not in os.environ:     # single-GPU rehearsal started without a launcher
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         backend = os.environ.get("HMG_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

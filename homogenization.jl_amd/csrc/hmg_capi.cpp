@@ -1118,6 +1118,7 @@ void coarse_setup(hmg_grid *g)
 }
 
 void coarse_probe_wait(hmg_grid *g);
+static void probe_unlist(hmg_grid *g);
 
 void coarse_pcg(hmg_grid *g)
 {
@@ -1175,7 +1176,8 @@ void coarse_pcg(hmg_grid *g)
         pr.budget = it;
         probe();
         HIPCHK(hipEventSynchronize(pr.ev));
-        pr.pending = false;
+        pr.pending = false;                        // judged right here
+        probe_unlist(g);
         const double done = pr.h[0], rr = pr.h[2], bb = pr.h[3];
         if (!std::isfinite(rr) || !std::isfinite(bb)) throw std::runtime_error("coarse PCG diverged (non-finite residual)");
         if (done != 0.0 || !(bb > 0.0)) break;
@@ -1237,7 +1239,8 @@ void judge_probes(hmg_ctx *c)
 {
     while (!c->probe_grids.empty()) {
         hmg_grid *g = c->probe_grids.back();
-        coarse_probe_wait(g);                      // (removes g from the list, may throw)
+        c->probe_grids.pop_back();                 // first: the verdict may throw, and a listed grid need not be pending
+        coarse_probe_wait(g);
     }
 }
 
