@@ -17,6 +17,8 @@ pp = ctypes.POINTER(ctypes.c_void_p)
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 EXCHANGE_END_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+P2P_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                          ctypes.POINTER(ctypes.c_int64))
 
 # name -> (restype, argtypes); every symbol declared in include/hmg.h
 SIGNATURES = {
@@ -83,6 +85,9 @@ SIGNATURES = {
     "hmg_grid_cut_buffer_doubles": (c_i64, [vp, c_int]),
     "hmg_grid_set_exchange_async": (c_int, [vp, EXCHANGE_FN, EXCHANGE_END_FN]),
     "hmg_grid_set_overlap": (c_int, [vp, c_int]),
+    "hmg_grid_set_exchange_p2p": (c_int, [vp, c_int, P2P_FN, P2P_FN, vp, c_i64]),
+    "hmg_grid_cut_stage_doubles": (c_i64, [vp]),
+    "hmg_grid_exchange_messages": (c_int, [vp, c_int, p_i64, c_i64, p_i64]),
     "hmg_ctx_set_scalar_bank": (c_int, [vp, vp]),
     "hmg_ctx_stream": (vp, [vp]),
     "hmg_comm_unique_id": (c_int, [vp]),

@@ -87,9 +87,25 @@ struct LevelBufs {
 struct CutKind {
     int64_t nglobal = 0;
     int64_t nentries = 0;
-    DevBuf<int64_t> gid;
+    std::vector<int64_t> gid;                    // host: global cut id of every local copy
+    std::vector<int32_t> seg;                    // host: segment / index inside it (sharers-only exchange), may be empty
+    std::vector<int64_t> sidx;
     DevBuf<int32_t> cell_lid;
     DevBuf<uint8_t> first;
+};
+
+// Exchange-buffer layout of one level (built at the first exchange on that level).
+//   global layout (all-reduce over every rank): [faces | edges | nodes], a run per GLOBAL cut id -- identical on all ranks;
+//   segment layout (exchange among the sharers only): this rank's segments one after the other, inside a segment faces,
+//   edges, nodes -- a segment has the same length and order on each of its members.
+struct CutLevel {
+    bool ready = false;
+    DevBuf<int64_t> pos[3];                      // per local cut copy: first buffer position of its run
+    int64_t ndoubles = 0;                        // buffer positions used on this level
+    // segment layout only:
+    std::vector<int64_t> ops;                    // messages, 4 numbers each: peer rank, buffer offset, count, stage offset
+    int64_t nstage = 0;                          // staging doubles (the peers' partial segments land there)
+    DevBuf<int64_t> plan;                        // k_seg_sum: nseg, then per segment off, size, nmembers, mtab offset; then mtab
 };
 
 }  // namespace
@@ -261,9 +277,16 @@ struct hmg_grid {
     int64_t part_nnodes = 0, part_ncells = 0;
     DevBuf<int32_t> d_nodes_g, d_owned, d_cells_gnode;
     CutKind cut[3];   // faces, edges, nodes
+    std::vector<std::unique_ptr<CutLevel>> cutlv;   // [nlevels]
+    bool sharers = false;                        // exchange among the sharers of each cut entity (segments) instead of one
+                                                 // all-reduce over the global cut buffer; needs a p2p transport (below)
     hmg_exchange_fn exchange = nullptr, scalar_sum = nullptr;
     hmg_exchange_fn ex_begin = nullptr;          // asynchronous form: begin issues the sum, end waits for it
     int (*ex_end)(void *) = nullptr;
+    hmg_p2p_fn p2p = nullptr, p2p_begin = nullptr;   // segment layout: the messages of one exchange (sync / begin; ex_end ends it)
+    double *stage = nullptr;
+    int64_t stage_cap = 0;
+    DevBuf<double> own_stage;
     bool overlap = true;
     DevBuf<int32_t> d_cells_cut, d_cells_inner;
     void *ex_user = nullptr;
@@ -748,6 +771,7 @@ void upload_operator(hmg_grid *g)
 }
 
 void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);   // defined below
+bool has_exchange(const hmg_grid *g) { return g->exchange || g->ex_begin || g->p2p || g->p2p_begin; }
 
 void set_slab(hmg_grid *g, const LevelDev &lv)
 {
@@ -809,7 +833,7 @@ void restrict_level(hmg_grid *g, int level_fine, const double *rf, double *bc)
 void interface_sum(hmg_grid *g, const LevelDev &lv, double *x, bool faces = true)
 {
     launch_interface_sum(g->ctx->L, lv, g->md, x, 0, faces);
-    if (g->exchange || g->ex_begin) exchange_cut(g, lv, x);
+    if (has_exchange(g)) exchange_cut(g, lv, x);
 }
 
 void scalar_sum(hmg_grid *g, int slot, int count)
@@ -820,8 +844,12 @@ void scalar_sum(hmg_grid *g, int slot, int count)
     }
 }
 
-int64_t cut_doubles(const hmg_grid *g, const LevelDev &lv);
+int64_t cut_doubles(hmg_grid *g, const LevelDev &lv);
 void cut_pack(hmg_grid *g, const LevelDev &lv, double *x, int unpack);
+void exchange_prepare(hmg_grid *g, const LevelDev &lv);
+void exchange_run(hmg_grid *g, const LevelDev &lv, bool async);
+void exchange_finish(hmg_grid *g, const LevelDev &lv, bool async);
+
 
 struct TimedRegion {   // HIP-event bracket of the finest-level operator applies (bench.py roofline)
     hmg_ctx *c;
@@ -867,8 +895,9 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     const double streams = 1.0 + (a.out ? 1.0 : 0.0) + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) +
                            (a.xacc ? 2.0 : 0.0) + (a.x3 ? 1.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
-    const int64_t ncut = g->exchange || g->ex_begin ? cut_doubles(g, lv) : 0;
-    const bool overlap = g->part && g->ex_begin && g->ex_end && g->overlap && ncut > 0 && g->md.ncells_cut > 0;
+    const int64_t ncut = has_exchange(g) ? cut_doubles(g, lv) : 0;
+    const bool overlap = g->part && (g->sharers ? g->p2p_begin != nullptr : g->ex_begin != nullptr) && g->ex_end && g->overlap &&
+                         ncut > 0 && g->md.ncells_cut > 0;
     auto launch = [&](const int32_t *list, int64_t n) {
         ApplyArgs b = a;
         b.cell_list = list;
@@ -908,18 +937,17 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
         interface_sum(g, lv, a.out, faces);
         return;
     }
-    need(ncut <= g->ex_cap, "exchange buffer too small for this level");
     launch(g->md.cells_cut, g->md.ncells_cut);
     launch_interface_sum(L, lv, g->md, a.out, 1);        // local copies of the cut entities
-    launch_fill(L, g->ex_buf, ncut, 0.0);
+    exchange_prepare(g, lv);
     cut_pack(g, lv, a.out, 0);
-    if (g->ex_begin(g->ex_user, g->ex_buf, ncut) != 0) throw std::runtime_error("exchange (begin) callback failed");
+    exchange_run(g, lv, true);
     if (g->md.ncells_inner > 0)                           // (an empty list must not read as "all cells")
         launch(g->md.cells_inner, g->md.ncells_inner);    // overlaps the sum over ranks
     tr.stop();
     launch_interface_sum(L, lv, g->md, a.out, 2, faces);
     sums();
-    if (g->ex_end(g->ex_user) != 0) throw std::runtime_error("exchange (end) callback failed");
+    exchange_finish(g, lv, true);
     cut_pack(g, lv, a.out, 1);
 }
 
@@ -1361,39 +1389,144 @@ void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);
 
 namespace {
 
-int64_t cut_doubles(const hmg_grid *g, const LevelDev &lv)
+// Buffer layout of one level (see CutLevel), built at the first exchange on that level and after every re-partition.
+CutLevel &cut_level(hmg_grid *g, const LevelDev &lv)
 {
-    return g->cut[0].nglobal * lv.nfi + g->cut[1].nglobal * lv.nei + g->cut[2].nglobal;
+    if (g->cutlv.size() != (size_t)g->nlevels) {
+        g->cutlv.clear();
+        for (int l = 0; l < g->nlevels; ++l) g->cutlv.emplace_back(new CutLevel);
+    }
+    CutLevel &C = *g->cutlv[lv.level - 1];
+    if (C.ready) return C;
+    const int64_t per[3] = {lv.nfi, lv.nei, 1};
+    hipStream_t st = g->ctx ? g->ctx->stream : nullptr;
+    std::vector<int64_t> pos;
+    if (!g->sharers) {
+        int64_t off = 0;
+        for (int k = 0; k < 3; ++k) {
+            pos.resize(g->cut[k].gid.size());
+            for (size_t e = 0; e < pos.size(); ++e) pos[e] = off + g->cut[k].gid[e] * per[k];
+            if (g->ctx) C.pos[k].upload(pos, st);
+            off += g->cut[k].nglobal * per[k];
+        }
+        C.ndoubles = off;
+    } else {
+        need(g->part != nullptr, "the sharers-only exchange needs the library's own partition analysis");
+        const Partition &P = *g->part;
+        const size_t nseg = P.segs.size();
+        std::vector<int64_t> soff(nseg + 1, 0);
+        for (size_t q = 0; q < nseg; ++q)
+            soff[q + 1] = soff[q] + P.segs[q].count[0] * per[0] + P.segs[q].count[1] * per[1] + P.segs[q].count[2] * per[2];
+        for (int k = 0; k < 3; ++k) {
+            pos.resize(g->cut[k].seg.size());
+            for (size_t e = 0; e < pos.size(); ++e) {
+                const Partition::Segment &S = P.segs[(size_t)g->cut[k].seg[e]];
+                const int64_t kbase = k == 0 ? 0 : k == 1 ? S.count[0] * per[0] : S.count[0] * per[0] + S.count[1] * per[1];
+                pos[e] = soff[(size_t)g->cut[k].seg[e]] + kbase + g->cut[k].sidx[e] * per[k];
+            }
+            if (g->ctx) C.pos[k].upload(pos, st);
+        }
+        C.ndoubles = soff[nseg];
+        // messages (one per segment and peer) and the summation plan: every member adds the members' partial segments in
+        // ascending rank order, its own from the buffer, the others' from the staging area -- the same bits on every member
+        C.ops.clear();
+        std::vector<int64_t> plan{(int64_t)nseg}, mtab;
+        plan.resize(1 + 4 * nseg);
+        int64_t stage = 0;
+        for (size_t q = 0; q < nseg; ++q) {
+            const Partition::Segment &S = P.segs[q];
+            const int64_t size = soff[q + 1] - soff[q];
+            plan[1 + 4 * q] = soff[q];
+            plan[2 + 4 * q] = size;
+            plan[3 + 4 * q] = (int64_t)S.members.size();
+            plan[4 + 4 * q] = (int64_t)mtab.size();
+            for (int32_t m : S.members) {
+                if (m == P.rank) {
+                    mtab.push_back(-1);
+                    continue;
+                }
+                mtab.push_back(stage);
+                if (size > 0) {
+                    C.ops.push_back(m);
+                    C.ops.push_back(soff[q]);
+                    C.ops.push_back(size);
+                    C.ops.push_back(stage);
+                }
+                stage += size;
+            }
+        }
+        C.nstage = stage;
+        for (size_t q = 0; q < nseg; ++q) plan[4 + 4 * q] += (int64_t)(1 + 4 * nseg);    // absolute offsets of the member tables
+        plan.insert(plan.end(), mtab.begin(), mtab.end());
+        if (g->ctx) C.plan.upload(plan, st);
+    }
+    C.ready = true;
+    return C;
 }
 
-// unpack = 0: buffer[cut id] <- first local copy;  unpack = 1: every local copy <- buffer[cut id]
+int64_t cut_doubles(hmg_grid *g, const LevelDev &lv) { return cut_level(g, lv).ndoubles; }
+
+// unpack = 0: buffer <- first local copy of every cut entity;  unpack = 1: every local copy <- buffer
 void cut_pack(hmg_grid *g, const LevelDev &lv, double *x, int unpack)
 {
     const Launch &L = g->ctx->L;
-    int64_t off = 0;
-    const int per[3] = {lv.nfi, lv.nei, 1};
+    CutLevel &C = cut_level(g, lv);
+    CutPackArgs a{};
     for (int k = 0; k < 3; ++k) {
-        if (g->cut[k].nentries && per[k])
-            launch_cut_pack(L, lv, k, g->cut[k].nentries, g->cut[k].gid.p, g->cut[k].cell_lid.p, g->cut[k].first.p,
-                            g->ex_buf + off, x, unpack);
-        off += g->cut[k].nglobal * per[k];
+        a.n[k] = g->cut[k].nentries;
+        a.pos[k] = C.pos[k].p;
+        a.cell_lid[k] = g->cut[k].cell_lid.p;
+        a.first[k] = g->cut[k].first.p;
+    }
+    launch_cut_pack(L, lv, a, g->ex_buf, x, unpack);
+}
+
+// The sum over ranks of the packed buffer, started (begin) and joined (finish) -- or both at once on the context's stream.
+// Global layout: one in-place all-reduce (positions no local copy writes must be zero: filled first).  Segment layout:
+// the partial segments travel to the other members, then every member adds them up in rank order.
+void exchange_prepare(hmg_grid *g, const LevelDev &lv)
+{
+    CutLevel &C = cut_level(g, lv);
+    need(C.ndoubles <= g->ex_cap, "exchange buffer too small for this level");
+    if (g->sharers)
+        need(C.nstage <= g->stage_cap, "staging buffer too small for this level");
+    else
+        launch_fill(g->ctx->L, g->ex_buf, C.ndoubles, 0.0);
+}
+
+void exchange_run(hmg_grid *g, const LevelDev &lv, bool async)
+{
+    CutLevel &C = cut_level(g, lv);
+    int rc;
+    if (g->sharers) {
+        hmg_p2p_fn f = async ? g->p2p_begin : g->p2p;
+        need(f != nullptr, "sharers-only exchange: no p2p transport set (hmg_grid_use_comm / hmg_grid_set_exchange_p2p)");
+        rc = f(g->ex_user, g->ex_buf, g->stage, (int64_t)C.ops.size() / 4, C.ops.data());
+    } else if (async)
+        rc = g->ex_begin(g->ex_user, g->ex_buf, C.ndoubles);
+    else if (g->exchange)
+        rc = g->exchange(g->ex_user, g->ex_buf, C.ndoubles);
+    else
+        rc = g->ex_begin(g->ex_user, g->ex_buf, C.ndoubles) || g->ex_end(g->ex_user);
+    if (rc != 0) throw std::runtime_error("exchange callback failed");
+}
+
+void exchange_finish(hmg_grid *g, const LevelDev &lv, bool async)
+{
+    if (async && g->ex_end(g->ex_user) != 0) throw std::runtime_error("exchange (end) callback failed");
+    if (g->sharers) {
+        CutLevel &C = cut_level(g, lv);
+        launch_seg_sum(g->ctx->L, C.plan.p, C.ndoubles, g->ex_buf, g->stage);
     }
 }
 
 void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x)
 {
-    const Launch &L = g->ctx->L;
-    const int64_t n = cut_doubles(g, lv);
-    if (n == 0) return;
-    need(n <= g->ex_cap, "exchange buffer too small for this level");
-    launch_fill(L, g->ex_buf, n, 0.0);
+    if (cut_doubles(g, lv) == 0) return;
+    exchange_prepare(g, lv);
     cut_pack(g, lv, x, 0);
-    if (g->exchange) {
-        if (g->exchange(g->ex_user, g->ex_buf, n) != 0) throw std::runtime_error("exchange callback failed");
-    } else {
-        if (g->ex_begin(g->ex_user, g->ex_buf, n) != 0 || g->ex_end(g->ex_user) != 0)
-            throw std::runtime_error("exchange callback failed");
-    }
+    exchange_run(g, lv, false);
+    exchange_finish(g, lv, false);
     cut_pack(g, lv, x, 1);
 }
 
@@ -1410,6 +1543,10 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -1433,6 +1570,10 @@ RcclApi &rccl()
     api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
     api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
     return api;
 }
@@ -1448,6 +1589,56 @@ void comm_allreduce(hmg_ctx *c, double *buf, int64_t n, hipStream_t s)
     nccl_check(rccl().AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c->comm, s), "ncclAllReduce");
     c->comm_calls += 1;
     c->comm_doubles += n;
+}
+
+// The messages of one sharers-only exchange as ONE grouped RCCL call: per message a send of this rank's partial segment and
+// a receive of the peer's into the staging area.  Two members of a segment list their common segments in the same order
+// (Partition::segs), and RCCL matches the k-th send a -> b with the k-th receive of b from a.
+void comm_p2p(hmg_ctx *c, double *buf, double *stage, int64_t nmsg, const int64_t *m, hipStream_t s)
+{
+    if (nmsg == 0) return;
+    int64_t sent = 0;
+    nccl_check(rccl().GroupStart(), "ncclGroupStart");
+    for (int64_t i = 0; i < nmsg; ++i) {
+        // (rehearsal of one rank's share of a larger partition: every peer is this rank itself -- a local copy stands in
+        //  for the link)
+        const int peer = c->comm_rehearsal ? c->comm_rank : (int)m[4 * i];
+        const size_t n = (size_t)m[4 * i + 2];
+        nccl_check(rccl().Send(buf + m[4 * i + 1], n, ncclDouble, peer, c->comm, s), "ncclSend");
+        nccl_check(rccl().Recv(stage + m[4 * i + 3], n, ncclDouble, peer, c->comm, s), "ncclRecv");
+        sent += (int64_t)n;
+    }
+    nccl_check(rccl().GroupEnd(), "ncclGroupEnd");
+    c->comm_calls += 1;
+    c->comm_doubles += sent;
+}
+
+int comm_p2p_sync(void *user, void *buf, void *stage, int64_t nmsg, const int64_t *msgs)
+{
+    hmg_grid *g = (hmg_grid *)user;
+    try {
+        comm_p2p(g->ctx, (double *)buf, (double *)stage, nmsg, msgs, g->ctx->stream);
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return 1;
+    }
+    return 0;
+}
+
+int comm_p2p_begin(void *user, void *buf, void *stage, int64_t nmsg, const int64_t *msgs)
+{
+    hmg_grid *g = (hmg_grid *)user;
+    hmg_ctx *c = g->ctx;
+    try {
+        HIPCHK(hipEventRecord(c->ev_packed, c->stream));             // the pack kernel
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+        comm_p2p(c, (double *)buf, (double *)stage, nmsg, msgs, c->comm_stream);
+        HIPCHK(hipEventRecord(c->ev_summed, c->comm_stream));
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return 1;
+    }
+    return 0;
 }
 
 // the built-in forms of the exchange callbacks (user = the grid): everything is enqueued on HIP streams, no host
@@ -1724,7 +1915,8 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
     HMG_END
 }
 
-static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const int64_t *gid, const int32_t *cell_lid);
+static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const int64_t *gid, const int32_t *cell_lid,
+                         const int32_t *seg, const int64_t *sidx);
 static void upload_levels(hmg_grid *g);
 
 // device side of the partition tables (after upload_mesh): cut lists, node ownership, global node ids of the cells
@@ -1732,10 +1924,10 @@ static void finish_partition(hmg_grid *g)
 {
     const Partition &P = *g->part;
     const MeshTables &M = g->cur();
-    for (int k = 0; k < 3; ++k) g->cut[k].nglobal = P.nglobal[k];
-    if (!g->ctx) return;
     for (int k = 0; k < 3; ++k)
-        set_cut_kind(g, k, P.nglobal[k], (int64_t)P.gid[k].size(), P.gid[k].data(), P.cell_lid[k].data());
+        set_cut_kind(g, k, P.nglobal[k], (int64_t)P.gid[k].size(), P.gid[k].data(), P.cell_lid[k].data(), P.seg_of[k].data(),
+                     P.seg_idx[k].data());
+    if (!g->ctx) return;
     g->d_nodes_g.upload(P.nodes_g, g->ctx->stream);
     g->d_owned.upload(P.owned_node, g->ctx->stream);
     std::vector<int32_t> cg(M.cells.size());
@@ -1901,6 +2093,27 @@ int hmg_grid_table_i32(const hmg_grid *g, int level, const char *which, int32_t 
                (int32_t)g->part->gid[0].size(), (int32_t)g->part->gid[1].size(), (int32_t)g->part->gid[2].size(),
                (int32_t)g->cur().ncut_face_pairs, (int32_t)g->cur().ncut_edge_groups, (int32_t)g->cur().ncut_node_groups,
                (int32_t)g->cur().cells_cut.size(), (int32_t)g->cur().cells_inner.size()};
+        src = &tmp;
+    } else if (w == "seg_ptr" || w == "seg_members" || w == "seg_counts") {
+        need(g->part != nullptr, "not a partitioned grid");
+        if (w == "seg_ptr") tmp.push_back(0);
+        for (const auto &S : g->part->segs) {
+            if (w == "seg_ptr")
+                tmp.push_back(tmp.back() + (int32_t)S.members.size());
+            else if (w == "seg_members")
+                tmp.insert(tmp.end(), S.members.begin(), S.members.end());
+            else
+                for (int k = 0; k < 3; ++k) tmp.push_back((int32_t)S.count[k]);
+        }
+        src = &tmp;
+    } else if (w == "cut_seg_faces" || w == "cut_seg_edges" || w == "cut_seg_nodes" || w == "cut_sidx_faces" ||
+               w == "cut_sidx_edges" || w == "cut_sidx_nodes") {
+        need(g->part != nullptr, "not a partitioned grid");
+        const int k = w.find("faces") != std::string::npos ? 0 : w.find("edges") != std::string::npos ? 1 : 2;
+        if (w.find("sidx") != std::string::npos)
+            tmp.assign(g->part->seg_idx[k].begin(), g->part->seg_idx[k].end());
+        else
+            tmp = g->part->seg_of[k];
         src = &tmp;
     } else if (w == "cut_gid_faces" || w == "cut_gid_edges" || w == "cut_gid_nodes" || w == "cut_ent_faces" ||
                w == "cut_ent_edges" || w == "cut_ent_nodes") {
@@ -2449,21 +2662,29 @@ int hmg_vcycle_up(hmg_grid *g, int level, int steps, hmg_vec **states)
 }
 
 // ---- multi-GPU hooks ------------------------------------------------------------------------------
-static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const int64_t *gid, const int32_t *cell_lid)
+static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const int64_t *gid, const int32_t *cell_lid,
+                         const int32_t *seg, const int64_t *sidx)
 {
     CutKind &c = g->cut[k];
     c.nglobal = nglobal;
     c.nentries = n;
-    std::vector<int64_t> hg(gid, gid + n);
+    c.gid.assign(gid, gid + n);
+    c.seg.clear();
+    c.sidx.clear();
+    if (seg && sidx) {
+        c.seg.assign(seg, seg + n);
+        c.sidx.assign(sidx, sidx + n);
+    }
     std::vector<int32_t> hc(cell_lid, cell_lid + n);
     std::vector<uint8_t> first(n, 0);
     std::unordered_map<int64_t, int> seen;
     for (int64_t i = 0; i < n; ++i) {
-        need(hg[i] >= 0 && hg[i] < nglobal, "cut id out of range");
+        need(c.gid[i] >= 0 && c.gid[i] < nglobal, "cut id out of range");
         need((hc[i] >> 3) >= 0 && (hc[i] >> 3) < g->md.ncells, "cut entry references a cell outside the grid");
-        if (seen.emplace(hg[i], 1).second) first[i] = 1;
+        if (seen.emplace(c.gid[i], 1).second) first[i] = 1;
     }
-    c.gid.upload(hg, g->ctx->stream);
+    g->cutlv.clear();                            // buffer layouts are rebuilt at the next exchange
+    if (!g->ctx) return;
     c.cell_lid.upload(hc, g->ctx->stream);
     c.first.upload(first, g->ctx->stream);
 }
@@ -2474,9 +2695,11 @@ int hmg_grid_set_cut(hmg_grid *g, int64_t ngf, int64_t nge, int64_t ngn, int64_t
 {
     HMG_TRY
     need(g != nullptr, "null grid");
-    set_cut_kind(g, 0, ngf, nlf, face_gid, face_cell_lid);
-    set_cut_kind(g, 1, nge, nle, edge_gid, edge_cell_lid);
-    set_cut_kind(g, 2, ngn, nln, node_gid, node_cell_lid);
+    // (a host-made cut list knows global ids only: all-reduce over the global cut buffer)
+    g->sharers = false;
+    set_cut_kind(g, 0, ngf, nlf, face_gid, face_cell_lid, nullptr, nullptr);
+    set_cut_kind(g, 1, nge, nle, edge_gid, edge_cell_lid, nullptr, nullptr);
+    set_cut_kind(g, 2, ngn, nln, node_gid, node_cell_lid, nullptr, nullptr);
     HMG_END
 }
 
@@ -2575,6 +2798,8 @@ int hmg_comm_sum_host(hmg_ctx *ctx, double *vals, int count)
     HMG_END
 }
 
+int64_t hmg_grid_cut_stage_doubles(const hmg_grid *cg);
+
 int hmg_grid_use_comm(hmg_grid *g)
 {
     HMG_TRY
@@ -2583,29 +2808,90 @@ int hmg_grid_use_comm(hmg_grid *g)
     need(g->part != nullptr, "not a partitioned grid (hmg_grid_create_partition)");
     need(g->ctx->comm_rehearsal || (g->part->nranks == g->ctx->comm_nranks && g->part->rank == g->ctx->comm_rank),
          "the grid's partition and the context's communicator disagree on rank / size");
+    // exchange among the sharers of each cut entity (grouped ncclSend / ncclRecv) unless HMG_EXCHANGE=allreduce asks for
+    // round 2's single all-reduce over the global cut buffer
+    const char *mode = std::getenv("HMG_EXCHANGE");
+    g->sharers = !(mode && std::string(mode) == "allreduce");
+    g->cutlv.clear();
     const int64_t cap = std::max<int64_t>(hmg_grid_cut_buffer_doubles(g, 0), 1);
     g->own_exbuf.alloc((size_t)cap);
     g->ex_buf = g->own_exbuf.p;
     g->ex_cap = cap;
+    const int64_t scap = std::max<int64_t>(hmg_grid_cut_stage_doubles(g), 1);
+    g->own_stage.alloc((size_t)scap);
+    g->stage = g->own_stage.p;
+    g->stage_cap = scap;
     g->ex_user = g;
-    g->exchange = comm_exchange;
+    g->exchange = comm_exchange;             // (the level-1 gather stays an all-reduce of the global nodal vector)
     g->scalar_sum = comm_exchange;           // (the same in-place sum, on the scalar bank)
     g->ex_begin = comm_exchange_begin;
     g->ex_end = comm_exchange_end;
+    g->p2p = comm_p2p_sync;
+    g->p2p_begin = comm_p2p_begin;
     HMG_END
 }
 
 void *hmg_ctx_stream(hmg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *g, int level)
+int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *cg, int level)
 {
+    hmg_grid *g = const_cast<hmg_grid *>(cg);
     if (!g || level < 0 || level > g->nlevels) return -1;
-    if (level == 0) {   // required capacity: max over levels and the coarse gather
-        int64_t n = g->part ? g->part->global.nnodes : 0;
-        for (int l = 0; l < g->nlevels; ++l) n = std::max(n, cut_doubles(g, g->ld[l]));
-        return n;
+    try {
+        if (level == 0) {   // required capacity: max over levels and the coarse gather
+            int64_t n = g->part ? g->part->global.nnodes : 0;
+            for (int l = 0; l < g->nlevels; ++l) n = std::max(n, cut_doubles(g, g->ld[l]));
+            return n;
+        }
+        return cut_doubles(g, g->ld[level - 1]);
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return -1;
     }
-    return cut_doubles(g, g->ld[level - 1]);
+}
+
+int64_t hmg_grid_cut_stage_doubles(const hmg_grid *cg)
+{
+    hmg_grid *g = const_cast<hmg_grid *>(cg);
+    if (!g) return -1;
+    try {
+        int64_t n = 0;
+        for (int l = 0; l < g->nlevels; ++l) n = std::max(n, cut_level(g, g->ld[l]).nstage);
+        return n;
+    } catch (const std::exception &e) {
+        last_error() = e.what();
+        return -1;
+    }
+}
+
+int hmg_grid_set_exchange_p2p(hmg_grid *g, int enabled, hmg_p2p_fn p2p, hmg_p2p_fn p2p_begin, void *device_stage_buf,
+                              int64_t stage_buf_doubles)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    need(!enabled || g->part != nullptr, "the sharers-only exchange needs a grid made by hmg_grid_create_partition");
+    g->sharers = enabled != 0;
+    g->cutlv.clear();
+    g->p2p = p2p;
+    g->p2p_begin = p2p_begin;
+    g->stage = (double *)device_stage_buf;
+    g->stage_cap = stage_buf_doubles;
+    HMG_END
+}
+
+int hmg_grid_exchange_messages(const hmg_grid *cg, int level, int64_t *out, int64_t cap, int64_t *count)
+{
+    HMG_TRY
+    hmg_grid *g = const_cast<hmg_grid *>(cg);
+    need(g && count, "null argument");
+    need(level >= 1 && level <= g->nlevels, "level out of range");
+    const CutLevel &C = cut_level(g, g->ld[level - 1]);
+    *count = (int64_t)C.ops.size();
+    if (out) {
+        need(cap >= *count, "output buffer too small");
+        std::copy(C.ops.begin(), C.ops.end(), out);
+    }
+    HMG_END
 }
 
 }  // extern "C"

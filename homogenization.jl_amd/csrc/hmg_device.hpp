@@ -221,8 +221,18 @@ void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const 
 void launch_integrate(const Launch &L, const LevelDev &lv, const MeshDev &mesh, int mode, int64_t nsub, const double *v,
                       const double *second, int slot);
 
-// multi-GPU cut exchange: unpack = 0 packs buf[gid] <- x (first local copy), 1 writes x <- buf[gid]
-void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nentries, const int64_t *gid,
-                     const int32_t *cell_lid, const uint8_t *first, double *buf, double *x, int unpack);
+// multi-GPU cut exchange, all three kinds (faces, edges, nodes) at once: unpack = 0 packs buf[pos[e] + k] <- x (first
+// local copy), 1 writes x <- buf[pos[e] + k]; pos[e] = first buffer position of the run of local cut copy e (layout:
+// CutLevel in hmg_capi.cpp)
+struct CutPackArgs {
+    int64_t n[3];                 // local cut copies per kind
+    const int64_t *pos[3];
+    const int32_t *cell_lid[3];   // cell * 8 + local entity
+    const uint8_t *first[3];      // 1: the first local copy of its entity (the one that is packed)
+};
+void launch_cut_pack(const Launch &L, const LevelDev &lv, const CutPackArgs &c, double *buf, double *x, int unpack);
+// sharers-only exchange: every buffer position of this rank's segments <- sum over the segment's members in ascending
+// rank order (own partial from buf, the others' from stage); plan: CutLevel::plan
+void launch_seg_sum(const Launch &L, const int64_t *plan, int64_t ndoubles, double *buf, const double *stage);
 
 }  // namespace hmg

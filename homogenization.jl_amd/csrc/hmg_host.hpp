@@ -207,6 +207,19 @@ struct Partition {
     int64_t nglobal[3] = {0, 0, 0};
     std::vector<int64_t> gid[3];
     std::vector<int32_t> cell_lid[3];
+    // The same cut entities grouped by WHO shares them (exchange among the sharers only): a segment is the set
+    // of cut entities with one set of member ranks -- at octants: a quarter of a cut plane (2 ranks), half an axis line
+    // (4 ranks), the centre node (8 ranks).  Only the segments this rank is a member of are listed, in an order every
+    // rank derives alike (first appearance in the global entity order: faces, edges, nodes), so that two members post
+    // their messages for each other in the same sequence.  Inside a segment: faces, then edges, then nodes, each in
+    // global entity order.
+    struct Segment {
+        std::vector<int32_t> members;        // ascending ranks, this rank among them (a rehearsal's segment may hold it alone)
+        int64_t count[3] = {0, 0, 0};        // entities per kind
+    };
+    std::vector<Segment> segs;
+    std::vector<int32_t> seg_of[3];          // per local cut copy (parallel to gid / cell_lid): its segment ...
+    std::vector<int64_t> seg_idx[3];         // ... and the entity's index among the segment's entities of that kind
 };
 
 // Splits `global` by owner[cell] and fills `local` (tables of this rank's cells, with Dirichlet mask,

@@ -1965,35 +1965,64 @@ void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// multi-GPU: pack one value per cut DOF (first local copy) / write the summed value to all copies
+// multi-GPU: pack one value per cut DOF (first local copy) / write the summed value to all copies -- faces, edges and
+// nodes in ONE launch per direction (29 exchanges per V-cycle: three launches each were 1 ms of launch-bound kernels)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_cut_pack(LevelDev lv, int kind, int64_t nentries, const int64_t *__restrict__ gid,
-           const int32_t *__restrict__ cell_lid, const uint8_t *__restrict__ first, double *buf, double *x, int unpack)
+__global__ void __launch_bounds__(256) k_cut_pack(LevelDev lv, CutPackArgs c, double *buf, double *x, int unpack)
 {
-    const int per = kind == 0 ? lv.nfi : kind == 1 ? lv.nei : 1;
-    const int off = kind == 0 ? lv.off_face : kind == 1 ? lv.off_edge : 0;
-    const int64_t total = nentries * per;
+    const int64_t t0 = c.n[0] * lv.nfi, t1 = t0 + c.n[1] * lv.nei, total = t1 + c.n[2];
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e = idx / per;
-        const int k = (int)(idx - e * per);
-        const int32_t v = cell_lid[e];
+        const int kind = idx < t0 ? 0 : idx < t1 ? 1 : 2;
+        const int per = kind == 0 ? lv.nfi : kind == 1 ? lv.nei : 1;
+        const int off = kind == 0 ? lv.off_face : kind == 1 ? lv.off_edge : 0;
+        const int64_t r = idx - (kind == 0 ? 0 : kind == 1 ? t0 : t1);
+        const int64_t e = r / per;
+        const int k = (int)(r - e * per);
+        const int32_t v = c.cell_lid[kind][e];
         double *a = x + (int64_t)(v >> 3) * lv.ld + off + (v & 7) * per + k;
-        double *b = buf + gid[e] * per + k;
+        double *b = buf + c.pos[kind][e] + k;
         if (unpack)
             *a = *b;
-        else if (first[e])
+        else if (c.first[kind][e])
             *b = *a;
     }
 }
 
-void launch_cut_pack(const Launch &L, const LevelDev &lv, int kind, int64_t nentries, const int64_t *gid,
-                     const int32_t *cell_lid, const uint8_t *first, double *buf, double *x, int unpack)
+void launch_cut_pack(const Launch &L, const LevelDev &lv, const CutPackArgs &c, double *buf, double *x, int unpack)
 {
-    const int per = kind == 0 ? lv.nfi : kind == 1 ? lv.nei : 1;
-    hipLaunchKernelGGL(k_cut_pack, dim3(strided_blocks(L, nentries * per, 1)), dim3(256), 0, L.stream, lv, kind,
-                       nentries, gid, cell_lid, first, buf, x, unpack);
+    const int64_t total = c.n[0] * lv.nfi + c.n[1] * lv.nei + c.n[2];
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_cut_pack, dim3(strided_blocks(L, total, 1)), dim3(256), 0, L.stream, lv, c, buf, x, unpack);
+    check_launch();
+}
+
+// plan: nseg, then per segment (offset, size, members, offset of its member table); member table: staging offset of every
+// member in ascending rank order, -1 for this rank
+__global__ void __launch_bounds__(256) k_seg_sum(const int64_t *__restrict__ plan, int64_t total, double *buf,
+                                                 const double *__restrict__ stage)
+{
+    const int nseg = (int)plan[0];
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int sgi = 0;
+        while (sgi + 1 < nseg && idx >= plan[1 + 4 * (sgi + 1)]) ++sgi;        // (a few dozen segments at most)
+        const int64_t off = plan[1 + 4 * sgi], d = idx - off;
+        const int nm = (int)plan[3 + 4 * sgi];
+        const int64_t *mt = plan + plan[4 + 4 * sgi];
+        double acc = 0.0;
+        for (int m = 0; m < nm; ++m) {
+            const int64_t so = mt[m];
+            const double v = so < 0 ? buf[idx] : stage[so + d];
+            acc = m == 0 ? v : acc + v;
+        }
+        buf[idx] = acc;
+    }
+}
+
+void launch_seg_sum(const Launch &L, const int64_t *plan, int64_t ndoubles, double *buf, const double *stage)
+{
+    if (ndoubles == 0) return;
+    hipLaunchKernelGGL(k_seg_sum, dim3(strided_blocks(L, ndoubles, 1)), dim3(256), 0, L.stream, plan, ndoubles, buf, stage);
     check_launch();
 }
 

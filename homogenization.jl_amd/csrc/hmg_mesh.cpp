@@ -8,6 +8,7 @@
 #include "hmg_host.hpp"
 
 #include <algorithm>
+#include <map>
 #include <array>
 #include <cmath>
 #include <cstdlib>
@@ -385,10 +386,15 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
     };
 
     // entities whose copies live on more than one rank get a global cut id (same on every rank)
+    part.segs.clear();
+    std::map<std::vector<int32_t>, int32_t> seg_by_members;
+    std::vector<int32_t> members;
     for (int kind = 0; kind < 3; ++kind) {
         part.nglobal[kind] = 0;
         part.gid[kind].clear();
         part.cell_lid[kind].clear();
+        part.seg_of[kind].clear();
+        part.seg_idx[kind].clear();
         if (kind == 0 && dim != 3) continue;
         const std::vector<Ent> &ents = kind == 0 ? glists.faces : kind == 1 ? glists.edges : glists.nodes;
         (void)nface;
@@ -399,10 +405,25 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
                 if (cown[ents[q].cell] != cown[ents[i].cell]) cut = true;
             if (!cut) return;
             const int64_t id = part.nglobal[kind]++;
+            members.clear();
+            for (size_t q = i; q < j; ++q) members.push_back(owner[ents[q].cell]);
+            std::sort(members.begin(), members.end());
+            members.erase(std::unique(members.begin(), members.end()), members.end());
+            if (!std::binary_search(members.begin(), members.end(), (int32_t)rank)) return;
+            auto it = seg_by_members.find(members);
+            if (it == seg_by_members.end()) {
+                it = seg_by_members.emplace(members, (int32_t)part.segs.size()).first;
+                part.segs.emplace_back();
+                part.segs.back().members = members;
+            }
+            const int32_t sg = it->second;
+            const int64_t idx = part.segs[sg].count[kind]++;
             for (size_t q = i; q < j; ++q)
                 if (owner[ents[q].cell] == rank) {
                     part.gid[kind].push_back(id);
                     part.cell_lid[kind].push_back(cell_l[ents[q].cell] * 8 + ents[q].lid);
+                    part.seg_of[kind].push_back(sg);
+                    part.seg_idx[kind].push_back(idx);
                 }
         });
     }

@@ -98,9 +98,16 @@ class Exchange:
     single-GPU rehearsals); the collectives are issued on the CONTEXT's stream, whatever torch's current stream is."""
 
     def __init__(self, ctx: api.Context, grid: PartitionedGrid, group=None, backend: str | None = None,
-                 comm_ranks: tuple | None = None):
+                 comm_ranks: tuple | None = None, sharers: bool | None = None):
         """comm_ranks = (rank, nranks) of the communicator when it differs from the grid's partition (rehearsal of one
-        rank's share of a larger partition, context option comm_rehearsal)."""
+        rank's share of a larger partition, context option comm_rehearsal).
+        sharers (default: on, HMG_EXCHANGE=allreduce switches it off): the cut DOFs are exchanged among the ranks that
+        share them only -- point-to-point messages per segment (include/hmg.h, hmg_grid_set_exchange_p2p) -- instead of one
+        all-reduce over the global cut buffer."""
+        import os as _os
+        if sharers is None:
+            sharers = _os.environ.get("HMG_EXCHANGE", "") != "allreduce"
+        self.sharers = sharers
         import torch
         import torch.distributed as dist
         self.dist, self.group, self.ctx = dist, group, ctx
@@ -188,12 +195,55 @@ class Exchange:
                 print("hmg exchange (end) failed:", e, flush=True)
                 return 1
 
+        def _p2p(user, ptr, sptr, nmsgs, msgs):
+            # one exchange among the sharers: every message = my partial segment to the peer, the peer's into the staging
+            # area.  gloo moves host tensors only: staged through the host (rehearsals; RCCL takes the in-library path).
+            try:
+                t0 = _time.perf_counter()
+                m = np.ctypeslib.as_array(msgs, shape=(int(nmsgs) * 4,)).reshape(-1, 4).copy() if nmsgs else np.zeros((0, 4), np.int64)
+                with torch.cuda.stream(self._stream):
+                    off0 = (ptr - self.buf.data_ptr()) // 8
+                    soff0 = (sptr - self.stage.data_ptr()) // 8 if nmsgs else 0
+                    host = self.dist.get_backend(self.group) != "nccl"
+                    ops, recvs = [], []
+                    for peer, off, cnt, soff in m:
+                        src = self.buf[off0 + off:off0 + off + cnt]
+                        dst = self.stage[soff0 + soff:soff0 + soff + cnt]
+                        if host:
+                            src = src.cpu()
+                            tmp = torch.empty(int(cnt), dtype=torch.float64)
+                            recvs.append((dst, tmp))
+                            dst = tmp
+                        ops.append(self.dist.P2POp(self.dist.isend, src, int(peer), self.group))
+                        ops.append(self.dist.P2POp(self.dist.irecv, dst, int(peer), self.group))
+                    if ops:
+                        for w in self.dist.batch_isend_irecv(ops):
+                            w.wait()
+                    for dst, tmp in recvs:
+                        dst.copy_(tmp)
+                self.seconds += _time.perf_counter() - t0
+                self.calls += 1
+                self.doubles += int(m[:, 2].sum()) if len(m) else 0
+                return 0
+            except Exception as e:
+                print("hmg p2p exchange failed:", e, flush=True)
+                return 1
+
         self._cb = (L.EXCHANGE_FN(_exchange), L.EXCHANGE_FN(_scalar), L.EXCHANGE_FN(_begin),
-                    L.EXCHANGE_END_FN(_end))
+                    L.EXCHANGE_END_FN(_end), L.P2P_FN(_p2p))
         ctx._keepalive.append(self._cb)                                     # the grid calls them as long as it lives
         L.check(lib.hmg_grid_set_exchange(grid.h, self._cb[0], self._cb[1], None,
                                           ctypes.c_void_p(self.buf.data_ptr()), n))
         L.check(lib.hmg_grid_set_exchange_async(grid.h, self._cb[2], self._cb[3]))
+        if sharers:
+            # (the blocking transport serves as `begin` as well: by the time it returns the messages have landed, and the
+            #  `end` callback above finds no work to wait for)
+            L.check(lib.hmg_grid_set_exchange_p2p(grid.h, 1, self._cb[4], self._cb[4], None, 0))
+            ns = max(int(lib.hmg_grid_cut_stage_doubles(grid.h)), 1)
+            self.stage = torch.zeros(ns, dtype=torch.float64, device=dev)
+            ctx._keepalive.append(self.stage)
+            L.check(lib.hmg_grid_set_exchange_p2p(grid.h, 1, self._cb[4], self._cb[4],
+                                                  ctypes.c_void_p(self.stage.data_ptr()), ns))
         grid._exchange = self
 
     def set_overlap(self, grid, enabled: bool):

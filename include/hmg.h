@@ -203,6 +203,22 @@ int hmg_grid_set_exchange(hmg_grid *grid, hmg_exchange_fn exchange, hmg_exchange
  * apply / interface sums of the cells that do not touch a partition cut (hmg_grid_set_overlap, default on). */
 int hmg_grid_set_exchange_async(hmg_grid *grid, hmg_exchange_fn begin, int (*end)(void *user));
 int hmg_grid_set_overlap(hmg_grid *grid, int enabled);
+/* Exchange among the sharers only (SURVEY 8e's cheaper alternative; the default of hmg_grid_use_comm).  The library groups
+ * the cut entities into SEGMENTS by the set of ranks that share them (octants: a quarter of a cut plane = 2 ranks, half an
+ * axis line = 4, the centre node = 8), lays this rank's segments out one after the other in the exchange buffer (a segment
+ * has the same length and order on each of its members) and, per exchange, hands the transport a list of messages
+ * msgs[4 i ..] = {peer rank, buffer offset, count, staging offset} (doubles): send device_buf[offset .. +count) to the
+ * peer, receive the peer's partial segment into device_stage[staging offset .. +count).  Two ranks list the segments they
+ * share in the same order, so the k-th message a -> b meets the k-th b <- a.  The library then adds the members' partials
+ * in ascending rank order (identical bits on every member).  p2p runs on the context's stream; p2p_begin only starts the
+ * messages and the `end` of hmg_grid_set_exchange_async joins them.  enabled = 0: back to the all-reduce over the global
+ * cut buffer.  hmg_grid_set_exchange still supplies user, the exchange buffer, scalar_sum and `exchange` (level-1 gather). */
+typedef int (*hmg_p2p_fn)(void *user, void *device_buf, void *device_stage, int64_t nmsgs, const int64_t *msgs);
+int hmg_grid_set_exchange_p2p(hmg_grid *grid, int enabled, hmg_p2p_fn p2p, hmg_p2p_fn p2p_begin, void *device_stage_buf,
+                              int64_t stage_buf_doubles);
+int64_t hmg_grid_cut_stage_doubles(const hmg_grid *grid);          /* staging capacity needed (max over levels) */
+/* the message list of one level: 4 int64 per message (count = numbers written) */
+int hmg_grid_exchange_messages(const hmg_grid *grid, int level, int64_t *out, int64_t cap, int64_t *count);
 /* level = 0: capacity needed for every level and for the coarse gather */
 int64_t hmg_grid_cut_buffer_doubles(const hmg_grid *grid, int level);
 void *hmg_ctx_scalar_bank(hmg_ctx *ctx);

@@ -5,6 +5,7 @@ solve) driven through the same cut tables the device pack/unpack kernels use.  T
 done with the oracle here (test infrastructure), the exchange is a real torch.distributed all_reduce.
 Checked against the serial oracle on the global mesh.
 """
+import ctypes
 import os
 import socket
 import sys
@@ -30,6 +31,7 @@ def _worker(rank, world, port, dim, shape, levels, q):
         import torch.distributed as dist
         import homogenization_jl_amd as hmg
         from homogenization_jl_amd import driver, dist as hdist
+        from homogenization_jl_amd import _lib as HL
         from oracle import oracle as O
         O.NTHREADS[0] = 1
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -117,11 +119,88 @@ def _worker(rank, world, port, dim, shape, levels, q):
             first[np.unique(gid, return_index=True)[1]] = True
             buf[torch.from_numpy(dst[first].ravel())] = torch.from_numpy(yl[rows[first], cols[first]].ravel())
             views[kind] = (rows, cols, dst)
+        yl_local = yl.copy(order="F")                                     # (kept for the second form of the exchange below)
         dist.all_reduce(buf)
         for kind, (rows, cols, dst) in views.items():
             yl[rows, cols] = buf[torch.from_numpy(dst.ravel())].numpy().reshape(dst.shape)
         err = np.abs(yl - ysum[:, g.local_cells]).max() / np.abs(ysum).max()
         assert err <= 1e-13, err
+        # ---- the same exchange among the SHARERS only (hmg_grid_set_exchange_p2p): segments = cut entities grouped by the
+        # set of ranks that share them; per segment and peer one message each way, then the members' partials are added in
+        # ascending rank order.  Layout, message list and order come from the library's tables, the transport is gloo.
+        HL.check(HL.load().hmg_grid_set_exchange_p2p(g.h, 1, HL.P2P_FN(0), HL.P2P_FN(0), None, 0))
+        sptr, smem = g.table_i32("seg_ptr"), g.table_i32("seg_members")
+        scnt = g.table_i32("seg_counts").reshape(-1, 3).astype(np.int64)
+        nseg = scnt.shape[0]
+        pers = np.array([nfi, nei, 1], dtype=np.int64)
+        size = scnt @ pers
+        soff = np.concatenate([[0], np.cumsum(size)])
+        assert int(HL.load().hmg_grid_cut_buffer_doubles(g.h, levels)) == soff[-1]
+        nmsg = ctypes.c_int64()
+        HL.check(HL.load().hmg_grid_exchange_messages(g.h, levels, None, 0, ctypes.byref(nmsg)))
+        msgs = np.zeros(nmsg.value, dtype=np.int64)
+        HL.check(HL.load().hmg_grid_exchange_messages(g.h, levels, msgs.ctypes.data_as(HL.p_i64), msgs.size, ctypes.byref(nmsg)))
+        msgs = msgs.reshape(-1, 4)
+        want_msgs = []
+        stage_off = 0
+        for sq in range(nseg):
+            members = smem[sptr[sq]:sptr[sq + 1]]
+            assert rank in members and list(members) == sorted(set(members.tolist()))
+            for m in members:
+                if m != rank:
+                    if size[sq] > 0:
+                        want_msgs.append((m, soff[sq], size[sq], stage_off))
+                    stage_off += size[sq]
+        assert [tuple(r) for r in msgs.tolist()] == [tuple(int(v) for v in r) for r in want_msgs]
+        assert int(HL.load().hmg_grid_cut_stage_doubles(g.h)) >= stage_off
+        buf2 = torch.zeros(max(int(soff[-1]), 1), dtype=torch.float64)
+        stage = torch.zeros(max(stage_off, 1), dtype=torch.float64)
+        views2 = {}
+        kbase = {"faces": np.zeros(nseg, np.int64), "edges": scnt[:, 0] * nfi, "nodes": scnt[:, 0] * nfi + scnt[:, 1] * nei}
+        for kind in ("faces", "edges", "nodes"):
+            sg = g.table_i32("cut_seg_" + kind).astype(np.int64)
+            sx = g.table_i32("cut_sidx_" + kind).astype(np.int64)
+            gid = g.table_i32("cut_gid_" + kind).astype(np.int64)
+            ce = g.table_i32("cut_ent_" + kind).astype(np.int64)
+            if per[kind] == 0 or sg.size == 0:
+                continue
+            k = np.arange(per[kind])
+            slots = offs[kind] + (ce & 7)[:, None] * per[kind] + k[None, :]
+            rows, cols = s2h[slots], (ce >> 3)[:, None] + 0 * k[None, :]
+            dst = (soff[sg] + kbase[kind][sg] + sx * per[kind])[:, None] + k[None, :]
+            first = np.zeros(gid.size, dtype=bool)
+            first[np.unique(gid, return_index=True)[1]] = True
+            buf2[torch.from_numpy(dst[first].ravel())] = torch.from_numpy(yl_local[rows[first], cols[first]].ravel())
+            views2[kind] = (rows, cols, dst)
+        ops = []
+        for peer, off, cnt, so in msgs:
+            ops.append(dist.P2POp(dist.isend, buf2[off:off + cnt].clone(), int(peer)))
+            ops.append(dist.P2POp(dist.irecv, stage[so:so + cnt], int(peer)))
+        if ops:
+            for wk in dist.batch_isend_irecv(ops):
+                wk.wait()
+        so = 0
+        for sq in range(nseg):                                              # (what k_seg_sum does)
+            members = smem[sptr[sq]:sptr[sq + 1]]
+            acc = None
+            for m in members:
+                if m == rank:
+                    v = buf2[soff[sq]:soff[sq + 1]].clone()
+                else:
+                    v = stage[so:so + size[sq]]
+                    so += size[sq]
+                acc = v.clone() if acc is None else acc + v
+            buf2[soff[sq]:soff[sq + 1]] = acc
+        yl2 = yl_local
+        for kind, (rows, cols, dst) in views2.items():
+            yl2[rows, cols] = buf2[torch.from_numpy(dst.ravel())].numpy().reshape(dst.shape)
+        err = np.abs(yl2 - ysum[:, g.local_cells]).max() / np.abs(ysum).max()
+        assert err <= 1e-13, err
+        # what it saves: doubles this rank sends vs the all-reduce buffer every rank pushes through the ring
+        sent = torch.tensor([float(msgs[:, 2].sum()) if len(msgs) else 0.0, float(tot)], dtype=torch.float64)
+        if world == 8:
+            assert sent[0].item() * 2 <= sent[1].item(), sent          # octants: at least a factor 2
+        HL.check(HL.load().hmg_grid_set_exchange_p2p(g.h, 0, HL.P2P_FN(0), HL.P2P_FN(0), None, 0))
         # first-copy masks give each DOF exactly once across ranks
         dup = g.table_i32("dupmask")
         uniq = np.ones_like(xl)

@@ -58,7 +58,7 @@ def test_budget_miss_is_reported_by_the_same_iteration_and_is_recoverable():
     the residual norm the driver takes right after vcycle!, src/examples/homogenized_coefficients.jl:286) -- not of the
     next V-cycle, and never silent for the last one.  The budget is dropped with it: repeating the V-cycle solves the
     slow, checked way and the run goes on.  (Forced here by tightening coarse_rtol under a budget that was counted for
-    1e-13: 1e-16 is below what FP64 Jacobi-PCG reaches at all.)"""
+    1e-13: the recurrence residual of CG does fall to 1e-40, but in three times the iterations -- twice the budget.)"""
     ctx = hmg.Context(0)
     try:
         L, w = 3, 10
@@ -68,7 +68,7 @@ def test_budget_miss_is_reported_by_the_same_iteration_and_is_recoverable():
         assert bl.last_iterations() > 20
         hmg.vcycle(g, bl, [op] * L, st, L, 3)                              # budgeted, fine
         hmg.norm_unique(st[-1].r)
-        ctx.set_option("coarse_rtol", 1e-16)
+        ctx.set_option("coarse_rtol", 1e-40)
         hmg.vcycle(g, bl, [op] * L, st, L, 3)                              # budgeted, cannot converge
         with pytest.raises(HmgError, match="did not reach coarse_rtol"):
             hmg.norm_unique(st[-1].r)                                      # same driver iteration
@@ -78,7 +78,7 @@ def test_budget_miss_is_reported_by_the_same_iteration_and_is_recoverable():
         assert np.isfinite(hmg.norm_unique(st[-1].r))
         assert bl.last_iterations() > 0 and bl.misses() == 1
         hmg.vcycle(g, bl, [op] * L, st, L, 3)                              # budgeted again
-        ctx.set_option("coarse_rtol", 1e-16)
+        ctx.set_option("coarse_rtol", 1e-40)
         hmg.vcycle(g, bl, [op] * L, st, L, 3)
         with pytest.raises(HmgError, match="did not reach coarse_rtol"):
             ctx.sync()                                                     # the last V-cycle of a run is judged too
