@@ -51,10 +51,17 @@ def cpu_baseline(sample_width, levels, steps_top):
     O.vcycle(impl, base, ops, st, levels, steps_top)
     dt = time.perf_counter() - t0
     dofs = impl.nf(levels) * m.nelements()
+    frac = m.nelements() / float(6 * 32 ** 3)
     return {"value": dofs / dt, "unit": "fine-DOF updates/s per V-cycle", "cores": int(threads), "kind": "port",
             "sample": f"1 V-cycle of the oracle (C restatement, cyclic cell distribution over {threads} OpenMP "
                       f"threads, serial interface sum) on a {sample_width}^3-cube sub-domain "
-                      f"({m.nelements()} of the workload's cells), L={levels}, {dt:.2f} s"}
+                      f"({m.nelements()} cells = {frac:.3g} of BASELINE config 3's 196608), L={levels}, {dt:.2f} s",
+            "sample_fraction_of_config3": frac,
+            # the WHOLE of config 3 through the same oracle, measured once on a GPU box's 16 host cores (needs ~90 GB of
+            # host memory and 66 s per V-cycle, too long for every bench run): tests/test_gpu_fullsize.py,
+            # profiles/r02_config3_driver_vs_oracle.txt
+            "full_size_reference": {"value": 1.287e9 / 66.8, "seconds_per_vcycle": 66.8, "cores": 16,
+                                    "source": "profiles/r02_config3_driver_vs_oracle.txt (round 2, one box)"}}
 
 
 def time_to_tolerance(ctx, hmg, driver, n, refinements, tolerance):

@@ -518,7 +518,7 @@ static void upload_levels(hmg_grid *g)
                         for (int t = 0; t < T.nterm; ++t) zero = zero && T.ctab[((size_t)(1 + f) * T.ndir + d) * T.nterm + t] == 0.0;
                         if (((absent[f] >> d) & 1u) && !zero) ok = false;   // a tap the kernel skips carries weight
                     }
-                // edges (pipelined kernel): an edge node keeps the taps both of its faces keep (edge_tap_mask)
+                // edges: an edge node keeps the taps both of its faces keep (edge_tap_mask)
                 static const int ef[6][2] = {{0, 1}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {2, 3}};
                 for (int e = 0; ok && e < T.nedge && T.nedge == 6; ++e)
                     for (int d = 0; d < T.ndir; ++d) {
@@ -1767,7 +1767,6 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_mass_only = 0;
     c->L.apply_unblocked = 0;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
-    c->L.apply_pipe = 0;   // experimental (measured slower than k_apply inside the V-cycle)
     live_contexts().push_back(c.get());
     *out = c.release();
     HMG_END
@@ -1809,8 +1808,6 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_unblocked = value != 0;
     else if (n == "apply_wg512")
         ctx->L.apply_wg512 = value != 0;
-    else if (n == "apply_pipe")
-        ctx->L.apply_pipe = (int)value;
     else if (n == "coarse_maxit")
         ctx->coarse_maxit = (int)value;
     else if (n == "coarse_check")

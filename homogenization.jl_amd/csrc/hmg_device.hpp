@@ -100,7 +100,6 @@ struct ApplyArgs {
     int64_t out_ld;        // column stride of out if it differs from the level's (slab restriction), else 0
     const int32_t *cell_list;   // optional: workgroup b works on cell cell_list[b] (ncell_list of them)
     int64_t ncell_list;
-    int64_t nwork;              // set by launch_apply_pipe: number of cells of this launch (walked with a grid stride)
 };
 
 struct CoarseDev {
@@ -128,19 +127,12 @@ struct Launch {
     int apply_unblocked;  // 1: node-per-thread interior sweep instead of the register-blocked one (dev / A-B knob)
     int apply_wg512;      // 1 (default): cells that would take the 1024-thread register-blocked instantiation take the 512-thread one:
                           // three workgroups (three columns in flight) per CU instead of two
-    int apply_pipe;       // 0 (default): k_apply; 1: plain applies of levels that qualify go through the pipelined persistent
-                          // kernel (hmg_apply_pipe.hip); 2: the fused CG passes without a source vector as well
 };
 
 // out = (src ? src : 0) + alpha * A x, then (use_mask) zero Dirichlet DOFs.  src may alias out.
 void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
                   const double *x, const double *src, double *out, int use_mask);
 size_t apply_lds_bytes(const LevelDev &lv);
-// pipelined persistent form of the same apply (hmg_apply_pipe.hip); `fused` selects the CG extras of ApplyArgs
-bool apply_pipe_supported(const LevelDev &lv);
-bool apply_pipe_takes(const LevelDev &lv, const ApplyArgs &a, bool fused);
-size_t apply_pipe_lds_bytes(const LevelDev &lv, bool with_coarse);
-void launch_apply_pipe(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a, bool fused);
 // Fused CG pass, see k_apply<.., FUSED>: the kernel (possibly over a cell list, several launches) leaves
 // per-cell partial sums in mesh.blockpart; the reduce step turns them into scal[slot_pap] = sum mult*xin*out and
 // scal[slot_rr] = sum xin*xin (slot_rr < 0: not wanted).  a.scal / a.mult / a.blockpart are filled in here.

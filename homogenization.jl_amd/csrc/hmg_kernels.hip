@@ -760,6 +760,20 @@ static size_t apply_lds_bytes_rb(const LevelDev &lv)   // register-blocked insta
     return sizeof(double) * (size_t)(WSZ_RB + lv.lds_g0 + lv.nf + lv.lds_g1);
 }
 
+// Every device base a kernel dereferences without a test of its own must be there: the kernels guard the OPTIONAL operands
+// (out of a fused pass, src, x2, xout, xacc, x3, xcoarse), not these.  (Round 2 lost a GPU box to a store through a null
+// base 0x4000 bytes in -- an experimental launch path without this check; a host throw costs nothing.)
+template <bool FUSED>
+static void check_apply_bases(const ApplyArgs &a, const MeshDev &mesh)
+{
+    if (!a.x) throw std::runtime_error("operator apply: null input vector");
+    if (!FUSED && !a.out) throw std::runtime_error("operator apply: a plain launch needs an output vector");
+    if (FUSED && (!a.blockpart || !a.scal)) throw std::runtime_error("operator apply: fused launch without its reduction scratch");
+    if (!mesh.coef) throw std::runtime_error("operator apply: no operator coefficients on the device (hmg_grid_set_operator)");
+    if ((a.flags & 1) && !mesh.dmask) throw std::runtime_error("operator apply: constraint requested without a Dirichlet mask");
+    if (a.xcoarse && !a.xout) throw std::runtime_error("operator apply: folded prolongation without xout");
+}
+
 template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false, bool CG = false>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
@@ -769,6 +783,7 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
     if (nblocks == 0) return;
+    check_apply_bases<FUSED>(a, mesh);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, a);
     check_launch();
 }
@@ -784,16 +799,13 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
         if (nblocks == 0) return;
+        check_apply_bases<FUSED>(a, mesh);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
                            mesh.slab);
         check_launch();
         return;
     }
     const int nf = lv.nf;
-    if (DIM == 3 && L.apply_threads == 0 && L.apply_pipe >= (FUSED ? 2 : 1) && !L.apply_unblocked && apply_pipe_takes(lv, a, FUSED)) {
-        launch_apply_pipe(L, lv, mesh, a, FUSED);
-        return;
-    }
     int nt = WD ? 0 : L.apply_threads;   // (the integral instantiations exist for the automatic workgroup sizes only)
     // (small cells are bound by the number of waves launched, not by their work: as few waves per cell as hold it)
     // (level 4, 165 nodes: one wave per cell in three passes beats three waves -- 32 instead of 10 cells in flight per CU,

@@ -1,4 +1,4 @@
-// Device-side building blocks shared by the kernels of hmg_kernels.hip and hmg_apply_pipe.hip: error checking,
+// Device-side building blocks of the kernels of hmg_kernels.hip: error checking,
 // reductions, LDS reads, addressing-word decoders, stencil evaluators (per node, per face run, register-blocked).
 #pragma once
 #include "hmg_device.hpp"

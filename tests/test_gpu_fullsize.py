@@ -1,8 +1,12 @@
 """
-BASELINE config 3 at full size (32^3 cubes x 6 tets, L = 6, 1.29e9 fine DOFs, 10.3 GB per vector) -- too large for
-the oracle, so parity is checked through size-independent properties of the operators:
-  linearity and symmetry of the local operator, constants in the kernel of the diffusion part, total mass,
-  interface-sum consistency, restriction = prolongation^T, multigrid contraction.
+BASELINE config 3 at full size (32^3 cubes x 6 tets, L = 6, 1.29e9 fine DOFs, 10.3 GB per vector).
+  * against the oracle at full size: one whole V-cycle (the oracle needs ~66 s on 16 host cores and ~90 GB of host
+    memory), interface sum / Dirichlet constraint / first-copy mask on all 1.29e9 entries (bit for bit), the operator
+    apply and the level transfers on sampled cells (they are cell-local);
+  * the optimised V-cycle against the plain sequence of the same library, bit for bit;
+  * size-independent properties of the operators: linearity and symmetry of the local operator, constants in the
+    kernel of the diffusion part, total mass, interface-sum consistency, restriction = prolongation^T, multigrid
+    contraction.
 """
 import numpy as np
 import pytest

@@ -1,7 +1,8 @@
 """
 GPU parity tests aimed at the instantiations the benchmark actually runs (BASELINE configs 3 and 5):
 
-  * 3D level 6 (Nf = 6545, the 1024-thread k_apply<3,1024,7,*>), directly against the oracle: apply for every
+  * 3D level 6 (Nf = 6545; the benchmark runs k_apply<3,512,13,*,6>, three 512-thread workgroups per CU), directly against
+    the oracle: apply for every
     workgroup size, residual + constraint, the slab restriction / prolongation of level 6, the fused CG smoother,
     and the two halves of a V-cycle level (hmg_vcycle_down / hmg_vcycle_up) which contain the pieces that only
     exist inside hmg_vcycle: the pre-smoother's dead tail, the local residual with two pending x-updates in its
@@ -36,7 +37,8 @@ def case6(oracle, ctx):
 
 @pytest.mark.parametrize("threads", [0, 1024, 640, 512])
 def test_l6_apply_every_workgroup_size(case6, ctx, threads):
-    """mul! on level 6 -- ref: src/apply_local_operators.jl:85-133; threads = 0 is the benchmark's choice (1024)."""
+    """mul! on level 6 -- ref: src/apply_local_operators.jl:85-133; threads = 0 is the benchmark's choice (512 threads,
+    register-blocked; 1024 / 640 / 512 force the plain instantiations of those sizes)."""
     c = case6
     lev = 6
     ctx.set_option("apply_threads", threads)
@@ -92,40 +94,6 @@ def test_l6_workgroup_shapes(case6, ctx, wg):
         assert relerr(dsts[-1].r.to_host(), sts[-1].r) <= 1e-8
     finally:
         ctx.set_option("apply_wg512", DEFAULT_WG512)
-
-
-@pytest.mark.parametrize("pipe", [1, 2])
-def test_l6_pipelined_kernel(case6, ctx, pipe):
-    """Option apply_pipe: the persistent software-pipelined form of the same apply (hmg_apply_pipe.hip: one workgroup per
-    CU, next cell's column prefetched into registers while the current one is evaluated, two LDS images).  Kept as an
-    experiment (it is not faster inside the V-cycle); same results: plain apply, residual with a source vector, and
-    (pipe = 2) the fused CG smoother."""
-    c = case6
-    lev = 6
-    ctx.set_option("apply_pipe", pipe)
-    try:
-        x, y = c.rand(lev), c.rand(lev)
-        want = y.copy(order="F")
-        c.O.mul(0.9, c.mesh, c.ops[lev - 1], x, want)
-        dx, dy = c.dev(lev, x), c.dev(lev, y)
-        hmg.mul(0.9, c.g, c.A, dx, dy)                                   # out = src + alpha A x
-        assert relerr(dy.to_host(), want) <= TOL
-        want2 = np.zeros_like(x, order="F")
-        c.O.mul(1.0, c.mesh, c.ops[lev - 1], x, want2)
-        c.O.apply_constraint(want2, lev, c.cons, c.impl)
-        dz = hmg.DeviceMatrix(c.g, lev)
-        hmg.apply_ex(1.0, c.g, dx, None, dz, constrain=True)             # out = A x, constraint
-        assert relerr(dz.to_host(), want2) <= TOL
-        st = _oracle_state(c, lev)
-        dst = hmg.LevelState(c.g, lev)
-        dst.x.from_host(st.x); dst.b.from_host(st.b)
-        c.O.smoothing_steps(3, c.impl, c.ops[lev - 1], st, lev)
-        hmg.smoothing_steps(3, c.g, c.A, dst, lev)
-        assert relerr(dst.x.to_host(), st.x) <= 1e-10
-        assert relerr(dst.r.to_host(), st.r) <= 1e-10
-        assert relerr(dst.p.to_host(), st.p) <= 1e-10
-    finally:
-        ctx.set_option("apply_pipe", 0)
 
 
 def test_l6_residual_and_constraint(case6):

@@ -16,14 +16,11 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--threads", type=int, default=None)
 ap.add_argument("--mode", default="ap")
 ap.add_argument("--unblocked", action="store_true", help="node-per-thread interior sweep (round-1 kernel) for A/B runs")
-ap.add_argument("--pipe", type=int, default=None, help="0: one workgroup per cell (k_apply); 1: pipelined persistent kernel for the plain applies; 2: also for the fused CG passes")
 ap.add_argument("--others", action="store_true", help="also time interface sum / vector kernels / transfer")
 a = ap.parse_args()
 ctx = hmg.Context(0)
 if a.threads is not None:
     ctx.set_option("apply_threads", a.threads)
-if a.pipe is not None:
-    ctx.set_option("apply_pipe", a.pipe)
 if a.unblocked:
     ctx.set_option("apply_unblocked", 1)
 L = a.levels

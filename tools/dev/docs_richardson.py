@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """ONE attempt: does the historical smoother of the reference's stale test -- damped Richardson with the
 omegas of test/local_operators.jl:45-49 (Tri: 0.2 on every level) -- reproduce the residual contraction the tutorial prints
-(docs/src/index.md:296-302: 0.9105 per cycle)?  Oracle only (CPU); everything but the smoother is the tutorial's setup."""
+(docs/src/index.md:296-302: 0.9105 per cycle)?  Oracle only (CPU); everything but the smoother is the tutorial's setup.
+
+RESULT (round 3): no.  With the tutorial's operator (sigma in {1, 9}, lambda = 1) Richardson diverges for omega = 0.2, 0.1 and 0.05
+(residual x 5e3, x 2e2, x 6 per cycle): those omegas belong to the SimpleDiffusion operator of the stale test (sigma = 1), whose
+spectrum is an order of magnitude smaller.  The published 0.9105 stays unexplained; the attempt is closed."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -14,14 +14,12 @@ from homogenization_jl_amd import _lib, driver
 ap = argparse.ArgumentParser()
 ap.add_argument("--width", type=int, default=32)
 ap.add_argument("--levels", type=int, default=6)
-ap.add_argument("--pipe", type=int, default=0, help="1/2: the pipelined persistent kernel (stamps: iteration start, loads issued, cell evaluated, next image written, barrier passed)")
 ap.add_argument("--wg512", type=int, default=1, help="option apply_wg512: 1 = three 512-thread workgroups per CU, 0 = two of 1024 threads")
 ap.add_argument("--nres", type=int, default=0, help="resident workgroups on the chip (0: 768 / 512 by --wg512; level 5: 2048)")
 ap.add_argument("--mode", default="ap", help="ap | res | cg0 (fused CG step 0: p = r stored, 24 B/DOF) | cg1 (fused CG step 1, 48 B/DOF)")
 a = ap.parse_args()
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhmg_hip_phase_timing.so")
 ctx = hmg.Context(0)
-ctx.set_option("apply_pipe", a.pipe)
 ctx.set_option("apply_wg512", a.wg512)
 L = a.levels
 base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, a.width, L, seed=0)
@@ -42,15 +40,6 @@ for rep in range(3):
         hmg.apply_ex(1.0, g, x, None, z, constrain=True)
 ctx.sync()
 raw = g.table_f64("phase_stamps")
-if a.pipe:
-    st = raw[2 * g.ncells():].reshape(-1, 8)[: g.ncells(), :5]
-    d = np.diff(st, axis=1) * 10.0 / 1e3
-    names = ["A issue next cell's loads", "B evaluate the cell", "C finish loads -> other image", "D barrier"]
-    print(f"cells {st.shape[0]}; kernel span {(st[:, 4].max() - st[:, 0].min()) * 10.0 / 1e6:.3f} ms")
-    for i, n in enumerate(names):
-        print(f"  {n:32s} mean {d[:, i].mean():7.2f} us   p10 {np.percentile(d[:, i], 10):7.2f}   p90 {np.percentile(d[:, i], 90):7.2f}")
-    print(f"  {'per cell (stamped)':32s} mean {(st[:, 4] - st[:, 0]).mean() * 10.0 / 1e3:7.2f} us")
-    raise SystemExit(0)
 st = raw[2 * g.ncells():].reshape(-1, 8)[: g.ncells(), :7]
 tick = 10.0  # ns per wall_clock64 tick (100 MHz)
 d = np.diff(st, axis=1) * tick / 1e3
