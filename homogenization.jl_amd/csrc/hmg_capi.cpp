@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -30,6 +31,17 @@ using namespace hmg;
 namespace {
 
 void release_pooled_memory();   // every live context hands its pooled level-vector blocks back (defined behind hmg_ctx)
+
+// Handles may be destroyed from another thread than the one that computes (finalizers of a garbage-collected host: Julia
+// runs them where it likes, Python's weakref.finalize on the collecting thread): reference counts, the registry of live
+// contexts and the pooled level-vector blocks are guarded by this lock.  (Recursive: a failed allocation inside a guarded
+// region hands the pools back.)  Everything else on one context is for one host thread at a time (include/hmg.h).
+std::recursive_mutex &lifetime_mutex()
+{
+    static std::recursive_mutex m;
+    return m;
+}
+using LifetimeLock = std::lock_guard<std::recursive_mutex>;
 
 template <class T>
 struct DevBuf {
@@ -167,6 +179,7 @@ namespace {
 
 void vec_pool_trim(hmg_ctx *c)
 {
+    LifetimeLock lock(lifetime_mutex());
     if (c->vec_pool.empty()) return;
     (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->vec_pool) (void)hipFree(b.second);
@@ -181,6 +194,7 @@ std::vector<hmg_ctx *> &live_contexts()
 
 void release_pooled_memory()
 {
+    LifetimeLock lock(lifetime_mutex());
     for (hmg_ctx *c : live_contexts()) vec_pool_trim(c);
 }
 
@@ -188,6 +202,7 @@ void release_pooled_memory()
 // same stream, or joined to it by events, before the block came back)
 double *vec_alloc(hmg_ctx *c, size_t bytes)
 {
+    LifetimeLock lock(lifetime_mutex());
     void *p = nullptr;
     for (size_t i = 0; i < c->vec_pool.size(); ++i)
         if (c->vec_pool[i].first == bytes) {
@@ -214,6 +229,7 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
 
 void vec_release(hmg_ctx *c, void *p, size_t bytes)
 {
+    LifetimeLock lock(lifetime_mutex());
     if (c->vec_pool_on && bytes > 0) {
         c->vec_pool.emplace_back(bytes, p);
         return;
@@ -1586,6 +1602,7 @@ void nccl_check(ncclResult_t r, const char *what)
 // in-place sum over ranks of n doubles, enqueued on `s`
 void comm_allreduce(hmg_ctx *c, double *buf, int64_t n, hipStream_t s)
 {
+    need(c->comm != nullptr, "this context's communicator has been destroyed (hmg_comm_destroy)");
     nccl_check(rccl().AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c->comm, s), "ncclAllReduce");
     c->comm_calls += 1;
     c->comm_doubles += n;
@@ -1597,6 +1614,7 @@ void comm_allreduce(hmg_ctx *c, double *buf, int64_t n, hipStream_t s)
 void comm_p2p(hmg_ctx *c, double *buf, double *stage, int64_t nmsg, const int64_t *m, hipStream_t s)
 {
     if (nmsg == 0) return;
+    need(c->comm != nullptr, "this context's communicator has been destroyed (hmg_comm_destroy)");
     int64_t sent = 0;
     nccl_check(rccl().GroupStart(), "ncclGroupStart");
     for (int64_t i = 0; i < nmsg; ++i) {
@@ -1630,6 +1648,7 @@ int comm_p2p_begin(void *user, void *buf, void *stage, int64_t nmsg, const int64
     hmg_grid *g = (hmg_grid *)user;
     hmg_ctx *c = g->ctx;
     try {
+        need(c->comm != nullptr, "this context's communicator has been destroyed (hmg_comm_destroy)");
         HIPCHK(hipEventRecord(c->ev_packed, c->stream));             // the pack kernel
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
         comm_p2p(c, (double *)buf, (double *)stage, nmsg, msgs, c->comm_stream);
@@ -1660,6 +1679,7 @@ int comm_exchange_begin(void *user, void *buf, int64_t n)
     hmg_grid *g = (hmg_grid *)user;
     hmg_ctx *c = g->ctx;
     try {
+        need(c->comm != nullptr, "this context's communicator has been destroyed (hmg_comm_destroy)");
         HIPCHK(hipEventRecord(c->ev_packed, c->stream));             // the pack kernels
         HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
         comm_allreduce(c, (double *)buf, n, c->comm_stream);
@@ -1687,6 +1707,7 @@ int comm_exchange_end(void *user)
 // =============================================================================================
 static void ctx_unref(hmg_ctx *ctx)
 {
+    LifetimeLock lock(lifetime_mutex());
     if (!ctx || --ctx->refs > 0) return;
     auto &lc = live_contexts();
     lc.erase(std::remove(lc.begin(), lc.end(), ctx), lc.end());
@@ -1707,6 +1728,7 @@ static void ctx_unref(hmg_ctx *ctx)
 
 static void grid_unref(hmg_grid *grid)
 {
+    LifetimeLock lock(lifetime_mutex());
     if (!grid || --grid->refs > 0) return;
     hmg_ctx *c = grid->ctx;
     if (c) {
@@ -1767,7 +1789,10 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_mass_only = 0;
     c->L.apply_unblocked = 0;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
-    live_contexts().push_back(c.get());
+    {
+        LifetimeLock lock(lifetime_mutex());
+        live_contexts().push_back(c.get());
+    }
     *out = c.release();
     HMG_END
 }
@@ -1907,7 +1932,10 @@ int hmg_grid_create(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const do
     build_mesh_tables(dim, nnodes, coords, ncells, cells, g->mesh_full);
     upload_levels(g.get());
     upload_mesh(g.get());
-    if (ctx) ctx->refs += 1;
+    if (ctx) {
+        LifetimeLock lock(lifetime_mutex());
+        ctx->refs += 1;
+    }
     *out = g.release();
     HMG_END
 }
@@ -1956,7 +1984,10 @@ static int create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, 
     upload_levels(g.get());
     upload_mesh(g.get());
     finish_partition(g.get());
-    if (ctx) ctx->refs += 1;
+    if (ctx) {
+        LifetimeLock lock(lifetime_mutex());
+        ctx->refs += 1;
+    }
     *out = g.release();
     HMG_END
 }
@@ -2219,7 +2250,10 @@ int hmg_vec_create(hmg_grid *g, int level, hmg_vec **out)
     ensure_reduce_scratch(g->ctx, (int64_t)lv.ld * g->md.ncells);
     v->d = vec_alloc(g->ctx, bytes);
     v->bytes = bytes;
-    g->refs += 1;
+    {
+        LifetimeLock lock(lifetime_mutex());
+        g->refs += 1;
+    }
     *out = v.release();
     HMG_END
 }
@@ -2235,7 +2269,10 @@ int hmg_vec_wrap(hmg_grid *g, int level, void *device_ptr, hmg_vec **out)
     v->own = false;
     v->alloc_cells = g->md.ncells;
     v->d = (double *)device_ptr;
-    g->refs += 1;
+    {
+        LifetimeLock lock(lifetime_mutex());
+        g->refs += 1;
+    }
     *out = v.release();
     HMG_END
 }
@@ -2768,6 +2805,15 @@ int hmg_comm_destroy(hmg_ctx *ctx)
         HIPCHK(hipStreamSynchronize(ctx->comm_stream));
         nccl_check(rccl().CommDestroy(ctx->comm), "ncclCommDestroy");
         ctx->comm = nullptr;
+        ctx->comm_nranks = 1;
+        ctx->comm_rank = 0;
+        // the second stream and its events go with the communicator (a later hmg_comm_init makes new ones); grids that
+        // still point at the built-in exchange callbacks fail cleanly in comm_allreduce / comm_p2p from now on
+        (void)hipEventDestroy(ctx->ev_packed);
+        (void)hipEventDestroy(ctx->ev_summed);
+        (void)hipStreamDestroy(ctx->comm_stream);
+        ctx->ev_packed = ctx->ev_summed = nullptr;
+        ctx->comm_stream = nullptr;
     }
     HMG_END
 }

@@ -9,6 +9,7 @@
 #include "../../include/hmg.h"
 #include "hmg_host.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -186,27 +187,33 @@ int hmg_conductivity_per_element(int dim, int64_t nnodes, const double *coords, 
         if ((dim != 2 && dim != 3) || !coords || !cells || !grid_shape || !sigma_grid || !offset || !sigma)
             throw std::runtime_error("bad argument");
         const int N = dim + 1;
-        std::vector<char> bad(1, 0);
+        std::atomic<int> bad{0};                 // 1: node id out of range, 2: centre outside the coefficient grid
         parallel_for(ncells, [&](int64_t a0, int64_t a1) {
             for (int64_t c = a0; c < a1; ++c) {
                 const int64_t *el = cells + c * N;
+                bool ok = true;
+                for (int l = 0; l < N; ++l) ok = ok && el[l] >= 1 && el[l] <= nnodes;
+                if (!ok) {                       // (checked before any coordinate is read)
+                    bad.store(1, std::memory_order_relaxed);
+                    continue;
+                }
                 int64_t lin = 0;
-                for (int a = 0; a < dim; ++a) {
-                    if (el[0] < 1 || el[0] > nnodes) bad[0] = 1;
+                for (int a = 0; a < dim && ok; ++a) {
                     double acc = coords[(el[0] - 1) * dim + a];
                     for (int l = 1; l < N; ++l) acc += coords[(el[l] - 1) * dim + a];
                     const int64_t ia = (int64_t)std::trunc(acc / N + offset[a]) - 1;
                     if (ia < 0 || ia >= grid_shape[a]) {
-                        bad[0] = 1;
-                        lin = 0;
-                        break;
-                    }
-                    lin = lin * grid_shape[a] + ia;
+                        if (bad.load(std::memory_order_relaxed) == 0) bad.store(2, std::memory_order_relaxed);
+                        ok = false;
+                    } else
+                        lin = lin * grid_shape[a] + ia;
                 }
+                if (!ok) continue;
                 for (int a = 0; a < dim; ++a) sigma[c * dim + a] = sigma_grid[lin * dim + a];
             }
         });
-        if (bad[0]) throw std::runtime_error("conductivity_per_element: a cell centre lies outside the coefficient grid");
+        if (bad.load() == 1) throw std::runtime_error("conductivity_per_element: a cell refers to a node id outside 1..nnodes");
+        if (bad.load() == 2) throw std::runtime_error("conductivity_per_element: a cell centre lies outside the coefficient grid");
     } catch (const std::exception &e) {
         return fail(e);
     }
@@ -220,9 +227,19 @@ int hmg_block_owner(int dim, int64_t nnodes, const double *coords, int64_t ncell
         if ((dim != 2 && dim != 3) || !coords || !cells || !blocks || !origin || !owner || !(width > 0.0))
             throw std::runtime_error("bad argument");
         const int N = dim + 1;
+        for (int a = 0; a < dim; ++a)
+            if (blocks[a] < 1) throw std::runtime_error("block_owner: every axis needs at least one block");
+        std::atomic<int> bad{0};
         parallel_for(ncells, [&](int64_t a0, int64_t a1) {
             for (int64_t c = a0; c < a1; ++c) {
                 const int64_t *el = cells + c * N;
+                bool ok = true;
+                for (int l = 0; l < N; ++l) ok = ok && el[l] >= 1 && el[l] <= nnodes;
+                if (!ok) {
+                    bad.store(1, std::memory_order_relaxed);
+                    owner[c] = -1;
+                    continue;
+                }
                 int64_t o = 0;
                 for (int a = 0; a < dim; ++a) {
                     double acc = coords[(el[0] - 1) * dim + a];
@@ -234,7 +251,7 @@ int hmg_block_owner(int dim, int64_t nnodes, const double *coords, int64_t ncell
                 owner[c] = (int32_t)o;
             }
         });
-        (void)nnodes;
+        if (bad.load()) throw std::runtime_error("block_owner: a cell refers to a node id outside 1..nnodes");
     } catch (const std::exception &e) {
         return fail(e);
     }

@@ -18,7 +18,10 @@
  *     1-based node ids with every cell's tuple ascending (src/implicit_fine_grid.jl:14).
  *   - device work is enqueued on the context's HIP stream; calls that return a scalar to the host
  *     synchronise that stream, all others are asynchronous.
- *   - all calls on one context must come from one host thread at a time.
+ *   - all COMPUTING calls on one context must come from one host thread at a time.  The hmg_*_destroy calls are the
+ *     exception: they may come from any thread at any time (finalizers) -- reference counts, the registry of contexts
+ *     and the pool of level-vector memory are guarded by a lock; the memory of a destroyed vector is reused only by
+ *     work enqueued later on the context's stream.
  */
 #ifndef HMG_H
 #define HMG_H
