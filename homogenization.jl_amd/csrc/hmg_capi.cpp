@@ -170,6 +170,7 @@ struct hmg_ctx {
     // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
     // the work per rank, the message sizes and the stream choreography are the real ones, the numbers are not)
     bool comm_rehearsal = false;
+    int64_t overlap_min_doubles = 131072;   // exchanges below 1 MiB are not overlapped (see apply_then_sum)
     // grids of this context whose last budgeted level-1 solve still has its probe in flight: judged at the next call that
     // synchronises the stream anyway (norms, dot products, integrals, hmg_ctx_sync, downloads)
     std::vector<struct hmg_grid *> probe_grids;
@@ -912,8 +913,11 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
                            (a.xacc ? 2.0 : 0.0) + (a.x3 ? 1.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
     const int64_t ncut = has_exchange(g) ? cut_doubles(g, lv) : 0;
+    // (overlapping costs launches -- the apply in two parts, the interface sums in two parts: worth it where the exchange
+    //  moves real data; on the small levels, launch-bound as they are, it only adds to the chain.  Rehearsal on one rank,
+    //  profiles/r03_partitioned_overhead.txt: every level overlapped +3.6 ms per V-cycle, none +0.0.)
     const bool overlap = g->part && (g->sharers ? g->p2p_begin != nullptr : g->ex_begin != nullptr) && g->ex_end && g->overlap &&
-                         ncut > 0 && g->md.ncells_cut > 0;
+                         ncut >= std::max<int64_t>(1, c->overlap_min_doubles) && g->md.ncells_cut > 0;
     auto launch = [&](const int32_t *list, int64_t n) {
         ApplyArgs b = a;
         b.cell_list = list;
@@ -1855,6 +1859,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->lean_post = value != 0;
     else if (n == "prolong_in_image" || n == "prolong_gather")   // (prolong_gather: the option's name in round 2)
         ctx->prolong_in_image = value != 0;
+    else if (n == "overlap_min_doubles")
+        ctx->overlap_min_doubles = value;
     else if (n == "comm_rehearsal")
         ctx->comm_rehearsal = value != 0;
     else if (n == "vec_pool") {

