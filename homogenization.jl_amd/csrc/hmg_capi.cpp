@@ -89,6 +89,8 @@ struct LevelBufs {
     DevBuf<uint32_t> pos32, pos32w, sweep32, par32, blk_word;
     DevBuf<uint64_t> par64;
     DevBuf<uint16_t> clpos;
+    DevBuf<uint32_t> rs_word;
+    DevBuf<double> rs_w;
     DevBuf<uint16_t> blk_slot;
     int nblk = 0, blk_R = 0;
     DevBuf<double> ctab;
@@ -144,6 +146,7 @@ struct hmg_ctx {
     bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
+    bool fold_restrict = true;     // V-cycle: the restriction rides in the epilogue of the local residual, which is then not stored
     bool prolong_in_image = true;  // folded prolongation, level 6: the coarse column is staged at the even nodes of the lattice image
                                    // instead of in LDS of its own behind it (three workgroups per CU stay resident)
     int device = 0;
@@ -719,6 +722,27 @@ static void upload_levels(hmg_grid *g)
                 }
                 B.clpos.upload(cl, s);
                 B.par64.upload(p64, s);
+                // restriction in the epilogue of the local residual (k_apply<.., RS>): addressing word of every coarse slot's
+                // fine node and the weights 1 / 0.5 on the taps that exist (nonzero mass entry of the class table) -- the
+                // weights of the stand-alone restriction (rtab above / launch_restrict_slab)
+                std::vector<int32_t> fslot((size_t)(m + 1) * (m + 1) * (m + 1), -1);
+                for (int q = 0; q < T.nf; ++q)
+                    fslot[((size_t)T.slot_ijk[3 * q + 2] * (m + 1) + T.slot_ijk[3 * q + 1]) * (m + 1) + T.slot_ijk[3 * q]] = q;
+                std::vector<uint32_t> rw((size_t)C.nf);
+                for (int c = 0; c < C.nf; ++c) {
+                    const int i = 2 * C.slot_ijk[3 * c], j = 2 * C.slot_ijk[3 * c + 1], k = 2 * C.slot_ijk[3 * c + 2];
+                    const int fs = fslot[((size_t)k * (m + 1) + j) * (m + 1) + i];
+                    if (fs < 0 || i > 127 || j > 127 || k > 127) throw std::runtime_error("restriction tables: bad coarse node");
+                    rw[c] = ((uint32_t)i & 127u) | (((uint32_t)j & 127u) << 7) | (((uint32_t)k & 127u) << 14) |
+                            ((uint32_t)T.slot_cls[fs] << 21);
+                }
+                std::vector<double> wts((size_t)T.ncls * T.ndir, 0.0);
+                for (int c = 0; c < T.ncls; ++c)
+                    for (int d = 0; d < T.ndir; ++d)
+                        wts[(size_t)c * T.ndir + d] =
+                            T.ctab[((size_t)c * T.ndir + d) * T.nterm + T.nterm - 1] != 0.0 ? (d == 0 ? 1.0 : 0.5) : 0.0;
+                B.rs_word.upload(rw, s);
+                B.rs_w.upload(wts, s);
             }
             B.rptr.upload(T.rptr, s);
             B.ridx.upload(T.ridx, s);
@@ -763,6 +787,8 @@ static void upload_levels(hmg_grid *g)
         D.par_b = B.par_b.p;
         D.par64 = B.par64.p;
         D.clpos = B.clpos.p;
+        D.rs_word = B.rs_word.p;
+        D.rs_w = B.rs_w.p;
         D.rptr = B.rptr.p;
         D.ridx = B.ridx.p;
         D.dphi = B.dphi.p;
@@ -910,7 +936,8 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     set_slab(g, lv);
     // algorithmic HBM streams of this launch: x in, out, + src, + x2 (p_old), + xout (p), + xacc (x read and write)
     const double streams = 1.0 + (a.out ? 1.0 : 0.0) + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) +
-                           (a.xacc ? 2.0 : 0.0) + (a.x3 ? 1.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
+                           (a.xacc ? 2.0 : 0.0) + (a.x3 ? 1.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0) +
+                           (a.rcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
     const int64_t ncut = has_exchange(g) ? cut_doubles(g, lv) : 0;
     // (overlapping costs launches -- the apply in two parts, the interface sums in two parts: worth it where the exchange
@@ -938,6 +965,12 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
             scalar_sum(g, slot_pap, 1);
         }
     };
+    if (!a.out && a.rcoarse) {       // local residual restricted in the kernel's epilogue: nothing is stored, summed or reduced
+        need(fused && !sum_out, "epilogue restriction belongs to the cell-local residual");
+        launch(nullptr, 0);
+        tr.stop();
+        return;
+    }
     if (!a.out) {                    // reductions only (dead-tail step of a pre-smoother): nothing to sum or exchange
         need(fused, "apply without an output vector");
         launch(nullptr, 0);
@@ -1325,8 +1358,11 @@ void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
 // zero initial guess on the coarser level.  Inside the library the pre-smoother's dead tail is dropped and its pending
 // x-update(s) ride in the load phase of the local residual (see smooth()); x, the local residual in r and the
 // coarse right-hand side are what the reference leaves, p and Ap are scratch.
-void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st)
+void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st, bool inside = false)
 {
+    // inside (hmg_vcycle): nobody can read this level's r before the post-smoother's first residual overwrites it
+    // (src/multigrid.jl:104-113), so where the apply kernel can restrict in its epilogue the cell-local residual is
+    // never stored -- the coarse right-hand side is the same to the last bit (option fold_restrict)
     hmg_vec **cur = st + 5 * (k - 1);
     hmg_vec **nxt = st + 5 * (k - 2);
     const Launch &L = g->ctx->L;
@@ -1359,6 +1395,14 @@ void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st)
         a.src = cur[1]->d;
         a.out = cur[2]->d;
         a.flags = 1;
+        if (g->ctx->fold_restrict && apply_restricts(L, lev(g, k))) {
+            if (inside) a.out = nullptr;          // (hmg_vcycle_down hands r back: there it is stored as well)
+            a.rcoarse = nxt[1]->d;
+            a.ldrc = lev(g, k - 1).ld;
+            apply_then_sum(g, lev(g, k), a, true, -1, -1, /*sum_out=*/false);
+            launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
+            return;
+        }
         apply_then_sum(g, lev(g, k), a, true, -1, -1, /*sum_out=*/false);
     } else {
         apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                        // local residual
@@ -1397,7 +1441,7 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st, bool 
         coarse_solve(g, cur[1], cur[0]);
         return;
     }
-    vcycle_down(g, k, steps, st);
+    vcycle_down(g, k, steps, st, /*inside=*/true);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st, false);
     vcycle_up(g, k, steps, st, g->ctx->lean_post ? (top ? 1 : 2) : 0);
 }
@@ -1851,6 +1895,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->swap_rp = value != 0;
     else if (n == "fold_prolong")
         ctx->fold_prolong = value != 0;
+    else if (n == "fold_restrict")
+        ctx->fold_restrict = value != 0;
     else if (n == "lazy_dead")
         ctx->lazy_dead = value != 0;
     else if (n == "fold_faces")

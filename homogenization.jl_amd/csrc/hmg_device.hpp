@@ -38,6 +38,10 @@ struct LevelDev {
     // folded prolongation with the coarse column staged at the EVEN nodes of the lattice image (3D levels with blocked tables):
     const uint64_t *par64;         // [nf]     LDS lattice position of parent a | of parent b << 16 | of the slot itself << 32
     const uint16_t *clpos;         // [nf_coarse] LDS lattice position (fine lattice, node (2i,2j,2k)) of every coarse slot
+    // restriction in the epilogue of the local residual (k_apply<.., RS>): per coarse slot the addressing word of its fine
+    // node (decode32w: i | j<<7 | k<<14 | cls<<21) and the weights 1 / 0.5 / 0 of the 15 taps per entity class
+    const uint32_t *rs_word;       // [nf_coarse]
+    const double *rs_w;            // [ncls * ndir]
     const int32_t *rptr, *ridx;    // [nf_coarse+1], [..] (level > 1)
     const double *dphi;            // [3*nf]
 };
@@ -88,6 +92,8 @@ struct ApplyArgs {
     int64_t ldc;           //   coarse-grid correction; column stride ldc), written back through xout
     const double *src;     // optional: out = src + alpha * A * xin
     double *out;
+    double *rcoarse;       // optional (k_apply RS instantiation): restrict_to!(rcoarse, P, out) in the epilogue -- column stride
+    int64_t ldrc;          //   ldrc; `out` itself may then be null (the cell-local residual is not stored at all)
     const double *scal;
     int s_num, s_den;
     double *blockpart;
@@ -133,6 +139,8 @@ struct Launch {
 void launch_apply(const Launch &L, const LevelDev &lv, const MeshDev &mesh, double alpha, double lambda,
                   const double *x, const double *src, double *out, int use_mask);
 size_t apply_lds_bytes(const LevelDev &lv);
+// can the fused apply of this level restrict its output in its epilogue (ApplyArgs::rcoarse)?
+bool apply_restricts(const Launch &L, const LevelDev &lv);
 // Fused CG pass, see k_apply<.., FUSED>: the kernel (possibly over a cell list, several launches) leaves
 // per-cell partial sums in mesh.blockpart; the reduce step turns them into scal[slot_pap] = sum mult*xin*out and
 // scal[slot_rr] = sum xin*xin (slot_rr < 0: not wanted).  a.scal / a.mult / a.blockpart are filled in here.

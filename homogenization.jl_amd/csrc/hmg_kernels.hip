@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 
 // WD: instantiation for the driver integrals (flags bit 3); CG: the folded prolongation stages the coarse column at the even nodes
 // of the lattice image itself (flags bit 6; cells that fill a third of the LDS have no room for it behind the image)
-template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false, bool CG = false>
+// RS: the results are restricted to the coarser level in the epilogue (ApplyArgs::rcoarse, see the end of the kernel)
+template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false, bool CG = false, bool RS = false>
 __global__ void __launch_bounds__(NT, NT >= 640 ? 8 : RB && NT == 512 ? 6 : 1)   // 2 x 1024 threads per CU need <= 64 VGPRs, 3 x 512: 80
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
@@ -199,7 +200,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // FUSED, optional: the prolongation of the coarse-grid correction, xin = x + P xcoarse (interpolate_and_sum_to!,
         // src/interpolation.jl:64-74: identity rows += 1.0 c[a], midpoints += 0.5 c[a], += 0.5 c[b] in the CSC
         // column order), from the cell's coarse column staged in LDS behind the lattice image
-        const double *ccol = FUSED && a.xcoarse ? a.xcoarse + cell * a.ldc : nullptr;
+        const double *ccol = FUSED && !RS && a.xcoarse ? a.xcoarse + cell * a.ldc : nullptr;
         // (CG, flags bit 6: no room behind the image -- see the in-image path below)
         constexpr bool cgather = FUSED && CG;
         double *cs = xs + nf + lv.lds_g1;
@@ -274,7 +275,8 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
         // A fused pass that reads nothing but its own column (CG step 0 with r itself as p: no x2 / xacc / x3 / coarse
         // column) takes the whole column in ONE batch like the plain apply -- one memory round trip instead of two.
-        const bool light = FUSED && NT >= 512 && !x2c && !xac && !x3c && !ccol;   // (level 5, 256 threads: the extra path costs a resident workgroup)
+        // (RS: the local residual with pending CG updates -- never a light pass, never a prolongation)
+        const bool light = !RS && FUSED && NT >= 512 && !x2c && !xac && !x3c && !ccol;   // (level 5, 256 threads: the extra path costs a resident workgroup)
         if (FUSED && light) {
             double xv[SPT];
             int lp[SPT];
@@ -299,7 +301,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             }
         }
         // ... and the dead step of a pre-smoother (reads r and p, forms p_new only in LDS, writes nothing): two streams
-        const bool light2 = FUSED && NT >= 512 && x2c && !xoc && !xac && !x3c && !ccol;
+        const bool light2 = !RS && FUSED && NT >= 512 && x2c && !xoc && !xac && !x3c && !ccol;
         if (FUSED && light2) {
             double xv[SPT], x2v[SPT];
             int lp[SPT];
@@ -406,7 +408,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
 
     // surface entities
     const int wbase = RB ? (1 + lv.nface + lv.nedge) * NDIR : 0;     // RB: the LDS table starts at the corners' rows
-    auto surface_node = [&](int t, uint32_t pw) {      // any class: weight row read from the LDS class table tap by tap
+    auto surface_node = [&](int t, uint32_t pw) -> double {   // any class: weight row read from the LDS class table tap by tap
         const double sv = sc ? sc[t] : 0.0;
         int L, len, A, B, cls;
         decode32<DIM>(pw, m, L, len, A, B, cls);
@@ -421,7 +423,20 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
             pap += (double)mu * ((wdot ? ctr + sv : ctr) * o);
         }
+        return o;
     };
+    // RS: every thread keeps what it evaluates (faces FI, edges NE, corner 1, interior NPASS x R values) for the epilogue
+    // (dead arrays in every other instantiation)
+    double kf[FI], ke[NE], kc = 0.0, ki[NPASS][RB ? RB : 1];
+    if constexpr (RS && RB != 0 && DIM == 3) {
+        // RS: the interior FIRST -- its sums stay in registers, and the surface runs need fewer registers beside them than the
+        // blocked walk would beside the surface results (no reduction of this launch depends on the order)
+        double w0e[15];
+#pragma unroll
+        for (int d = 0; d < NDIR; ++d) w0e[d] = readlane_f64(wv, d);
+        if (tid < nsw) interior_block_keep<RB ? RB : 1, FUSED>(w0e, xs, m, nf >> 1, q0, s0, sc, oc, ki[0]);
+        if (NPASS > 1 && tid + NT < nsw) interior_block_keep<RB ? RB : 1, FUSED>(w0e, xs, m, nf >> 1, q1, s1, sc, oc, ki[NPASS - 1]);
+    }
     if (RB) {
         if (DIM == 3) {
             const bool fdir = (dm >> face) & 1u;
@@ -433,13 +448,13 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             if (face >= 4)
                 ;
             else if (face == 0)
-                face_items<0, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
+                face_items<0, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
             else if (face == 1)
-                face_items<1, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
+                face_items<1, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
             else if (face == 2)
-                face_items<2, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
+                face_items<2, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
             else
-                face_items<3, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot);
+                face_items<3, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 if (edge[q] < 0) continue;
@@ -449,15 +464,15 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 const double nop1[1] = {0.0};
                 const int wl = 32 + 16 * q;
                 switch (edge[q]) {
-                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
-                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot); break;
+                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
                 }
             }
-            if (wave == NW - 1 && lane < lv.ncorner) surface_node(lane, cw);
+            if (wave == NW - 1 && lane < lv.ncorner) kc = surface_node(lane, cw);
         }
     } else {
         const int nit_surf = (nsurf + NT - 1) / NT;
@@ -477,6 +492,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     if (RB) {
         // register-blocked interior: one pass (the host selects this instantiation only if nblk <= NT), its word
         // was fetched before the barrier
+        if constexpr (!RS) {
         if (DIM == 3 && tid < nsw) {
             if (sc)
                 interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap, wdot);
@@ -488,6 +504,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q1, s1, sc, oc, pap, wdot);
             else
                 interior_block<RB ? RB : 1, FUSED, false>(w0, xs, m, nf >> 1, q1, s1, sc, oc, pap);
+        }
         }
     } else {
         const int nit_sweep = (nsw + NT - 1) / NT;
@@ -512,6 +529,65 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
     }
     HMG_STAMP(5);
+    if constexpr (RS && RB != 0 && DIM == 3) {
+        // Restriction in the epilogue (restrict_to!, src/interpolation.jl:52-62, of the cell-local residual this launch has just
+        // formed -- src/multigrid.jl:104-105): the results go from the registers into the lattice image, which nobody reads
+        // any more behind the barrier, and the coarse right-hand side is the 15-point sum 1 x own + 0.5 x neighbours at the
+        // EVEN lattice nodes, taps that leave the cell weighted 0 -- tap for tap the arithmetic of the stand-alone restriction
+        // (k_apply_slab with flags bit 2), so the coarse vector is the same to the last bit.  The residual itself need not go
+        // to HBM at all (oc == nullptr): 16 B per fine DOF and one launch less per V-cycle.
+        __syncthreads();
+        if (face < 4) {
+#pragma unroll
+            for (int q = 0; q < FI; ++q)
+                if (ft0 + q * 64 + lane < lv.nfi) xs[fw[q] & 0xffffu] = kf[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NE; ++q)
+            if (edge[q] >= 0 && lane < lv.nei) xs[ew[q][0] & 0xffffu] = ke[q];
+        if (wave == NW - 1 && lane < lv.ncorner) xs[cw & 0xffffu] = kc;
+        {
+            int pos[RB ? RB : 1];
+            if (tid < nsw) {
+                block_positions<RB ? RB : 1>(m, q0, pos);
+                const int nv = (int)(q0 >> 28);
+#pragma unroll
+                for (int r = 0; r < (RB ? RB : 1); ++r)
+                    if (r < nv) xs[pos[r]] = ki[0][r];
+            }
+            if (NPASS > 1 && tid + NT < nsw) {
+                block_positions<RB ? RB : 1>(m, q1, pos);
+                const int nv = (int)(q1 >> 28);
+#pragma unroll
+                for (int r = 0; r < (RB ? RB : 1); ++r)
+                    if (r < nv) xs[pos[r]] = ki[NPASS - 1][r];
+            }
+        }
+        __syncthreads();
+        double *rc = a.rcoarse + cell * a.ldrc;
+        for (int c = tid; c < lv.nf_coarse; c += NT) {
+            int L, len, A, B, cls, k;
+            decode32w(lv.rs_word[c], m, L, len, A, B, cls, k);
+            const double *w = lv.rs_w + cls * NDIR;
+            auto at = [&](int off) { return lds_ld(xs + max(L + off, 0)); };
+            double acc = w[0] * lds_ld(xs + L);
+            acc += w[1] * lds_ld(xs + L + 1);
+            acc += w[2] * at(-1);
+            acc += w[3] * lds_ld(xs + L + len - 1);
+            acc += w[4] * at(-len);
+            acc += w[5] * lds_ld(xs + L + len);
+            acc += w[6] * at(-len - 1);
+            acc += w[7] * lds_ld(xs + L + A - len);
+            acc += w[8] * at(len + 1 - B);
+            acc += w[9] * lds_ld(xs + L + A - 1);
+            acc += w[10] * at(1 - B);
+            acc += w[11] * lds_ld(xs + L + A);
+            acc += w[12] * at(-B);
+            acc += w[13] * lds_ld(xs + L + A + 1 - len);
+            acc += w[14] * at(len - B);
+            rc[c] = 0.0 + acc;               // (the stand-alone kernel adds its absent source value first: 0 + acc)
+        }
+    }
     if (FUSED) {
         __syncthreads();                     // W / xs no longer read: reuse the front of LDS for the reduction
         const double s_pap = block_sum(pap, smem);
@@ -755,6 +831,14 @@ size_t apply_lds_bytes(const LevelDev &lv)
     return sizeof(double) * (size_t)(WSZ + lv.lds_g0 + lv.nf + lv.lds_g1);
 }
 
+bool apply_restricts(const Launch &L, const LevelDev &lv)
+{
+    // the conditions under which launch_apply_dim reaches the 512-thread register-blocked instantiations (level 6)
+    return lv.dim == 3 && apply_lds_bytes(lv) <= 160 * 1024 && L.apply_threads == 0 && lv.nf > 2048 && lv.blk_R == 6 &&
+           lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked && L.apply_wg512 &&
+           lv.nfi <= 512 && lv.rs_word && lv.rs_w && lv.nf_coarse > 0;
+}
+
 static size_t apply_lds_bytes_rb(const LevelDev &lv)   // register-blocked instantiations: only the corners' weight rows in LDS
 {
     return sizeof(double) * (size_t)(WSZ_RB + lv.lds_g0 + lv.nf + lv.lds_g1);
@@ -768,16 +852,18 @@ static void check_apply_bases(const ApplyArgs &a, const MeshDev &mesh)
 {
     if (!a.x) throw std::runtime_error("operator apply: null input vector");
     if (!FUSED && !a.out) throw std::runtime_error("operator apply: a plain launch needs an output vector");
+    if (a.rcoarse && a.ldrc <= 0) throw std::runtime_error("operator apply: epilogue restriction without the coarse column stride");
     if (FUSED && (!a.blockpart || !a.scal)) throw std::runtime_error("operator apply: fused launch without its reduction scratch");
     if (!mesh.coef) throw std::runtime_error("operator apply: no operator coefficients on the device (hmg_grid_set_operator)");
     if ((a.flags & 1) && !mesh.dmask) throw std::runtime_error("operator apply: constraint requested without a Dirichlet mask");
     if (a.xcoarse && !a.xout) throw std::runtime_error("operator apply: folded prolongation without xout");
 }
 
-template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false, bool CG = false>
+template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false, bool CG = false, bool RS = false>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
-    auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD, CG>;
+    auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD, CG, RS>;
+    if (a.rcoarse && !RS) throw std::runtime_error("operator apply: this instantiation cannot restrict in its epilogue");
     if (FUSED && a.xcoarse && !CG) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -844,6 +930,9 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
                     lv.nf <= 13 * 512 && lv.nf_coarse <= 2 * 512)
                     launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0, false, FUSED && DIM == 3>(L, lv, mesh, a,
                                                                                                       apply_lds_bytes_rb(lv));
+                else if (FUSED && DIM == 3 && a.rcoarse && lv.rs_word && lv.rs_w && !a.xcoarse)   // (own instantiation again)
+                    launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0, false, false, FUSED && DIM == 3>(
+                        L, lv, mesh, a, apply_lds_bytes_rb(lv));
                 else
                     launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
                 return;

@@ -207,8 +207,9 @@ template <uint32_t M, int NITEM, bool FUSED>
 __device__ __forceinline__ void class_items(double wv, int wlane0, const double *xs, int m, int nfi, int slot_base, int t0,
                                             const uint32_t (&fw)[NITEM], bool dirichlet, double mult, const double *sc,
                                             double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre,
-                                            bool wdot = false)
+                                            bool wdot = false, double *keep = nullptr)
 {
+    // keep (optional, NITEM entries): the results are handed back as well (restriction in the epilogue)
     // wdot: the source value multiplies instead of being added: out = alpha A x, pap += mult (x + src) out
     // wv: the class weight row, spread over the lanes wlane0 .. wlane0 + 14 of this wave; M: the taps that exist
     double w[15];
@@ -246,6 +247,7 @@ __device__ __forceinline__ void class_items(double wv, int wlane0, const double 
                 if (FUSED) pap += mult * ((wdot ? ctr + sv : ctr) * o);
             }
             if (!FUSED || oc) oc[t] = o;
+            if (keep) keep[q] = o;
         }
     }
 }
@@ -254,10 +256,10 @@ template <int F, int NITEM, bool FUSED>
 __device__ __forceinline__ void face_items(double wv, int wlane0, const double *xs, int m, int nfi, int slot_base, int t0,
                                            const uint32_t (&fw)[NITEM], bool dirichlet, double mult, const double *sc,
                                            double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre,
-                                           bool wdot = false)
+                                           bool wdot = false, double *keep = nullptr)
 {
     class_items<face_tap_mask(F), NITEM, FUSED>(wv, wlane0, xs, m, nfi, slot_base, t0, fw, dirichlet, mult, sc, oc, pap, lane,
-                                                pre, use_pre, wdot);
+                                                pre, use_pre, wdot, keep);
 }
 
 // Edge e of the reference simplex lies on two faces (edge order of the reference: (1,2) (1,3) (1,4) (2,3) (2,4) (3,4) =
@@ -294,11 +296,12 @@ __device__ __forceinline__ void block_slots(int m, uint32_t word, int slot0, int
 
 // acc[r] holds the value the sum of node r starts from (0, or the source value for out = src + alpha A x).
 // WDOT: wsv[r] is added to the node's own value in the p.Ap-type sum (driver integrals: (v + w) . M v).
-template <int R, bool FUSED, bool WDOT = false>
+template <int R, bool FUSED, bool WDOT = false, bool KEEP = false>
 __device__ __forceinline__ void interior_block_core(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
                                                     int slot0, double *oc, double &pap, double (&acc)[R],
                                                     const double *wsv = nullptr)
 {
+    // KEEP: the finished sums stay in acc[] for the caller (restriction in the epilogue) and p.Ap is not formed
     const int L = (int)(word & 0xffffu), j = (int)((word >> 16) & 63u), k0 = (int)((word >> 22) & 63u);
     const int nv = (int)(word >> 28);
     const int n0 = m - k0;
@@ -330,16 +333,17 @@ __device__ __forceinline__ void interior_block_core(const double (&w)[15], const
             t += w[13] * v1;
             t += w[9] * v2;
             t += w[11] * v3;
+            if (KEEP) acc[s - 2] = t;
             if (s - 2 < nv) {
                 if (!FUSED || oc) oc[slot] = t;
-                if (FUSED) pap += (WDOT ? ctr[s - 2] + wsv[s - 2] : ctr[s - 2]) * t;   // (the CG passes have no src)
+                if (FUSED && !KEEP) pap += (WDOT ? ctr[s - 2] + wsv[s - 2] : ctr[s - 2]) * t;   // (the CG passes have no src)
             }
             slot += ds;
             ds -= n0 - s;                   // n0 - 2 - r, r = s - 2
         }
         if (s >= 1 && s <= R) {             // the plane of node s-1
             double t = acc[s - 1];
-            ctr[s - 1] = v3;
+            if (!KEEP) ctr[s - 1] = v3;
             t += w[0] * v3;
             t += w[1] * v4;
             t += w[2] * v2;
@@ -367,6 +371,40 @@ __device__ __forceinline__ void interior_block_core(const double (&w)[15], const
 }
 
 // SRC: out = src + alpha A x -- the R source values are loaded first (their global latency hides behind the planes).
+// The LDS lattice positions of the R nodes of a block (the recurrence of interior_block_core).
+template <int R>
+__device__ __forceinline__ void block_positions(int m, uint32_t word, int (&pos)[R])
+{
+    const int L = (int)(word & 0xffffu), j = (int)((word >> 16) & 63u), n0 = m - (int)((word >> 22) & 63u);
+    int delta = (int)(__umul24((uint32_t)(n0 + 2), (uint32_t)(n0 + 3)) >> 1) - j;
+    int q = L - delta;
+#pragma unroll
+    for (int s = 0; s < R + 1; ++s) {
+        if (s >= 1) pos[s - 1] = q;
+        q += delta;
+        delta -= n0 + 2 - s;
+    }
+}
+
+// ... with the results handed back in res[] (KEEP form: out = src + alpha A x, no p.Ap)
+template <int R, bool FUSED>
+__device__ __forceinline__ void interior_block_keep(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
+                                                    int slot0, const double *sc, double *oc, double (&res)[R])
+{
+    if (sc) {
+        int slot[R];
+        block_slots<R>(m, word, slot0, slot);
+        const int nv = (int)(word >> 28);
+#pragma unroll
+        for (int r = 0; r < R; ++r) res[r] = r < nv ? sc[slot[r]] : 0.0;
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) res[r] = 0.0;
+    }
+    double pap = 0.0;
+    interior_block_core<R, FUSED, false, true>(w, xs, m, safe, word, slot0, oc, pap, res);
+}
+
 template <int R, bool FUSED, bool SRC>
 __device__ __forceinline__ void interior_block(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
                                                int slot0, const double *sc, double *oc, double &pap, bool wdot = false)

@@ -153,7 +153,7 @@ def test_l6_smoothing_steps(case6, steps):
 
 
 DEFAULT_WG512 = 1      # hmg_ctx_create's default (see hmg_ctx_set_option in include/hmg.h)
-OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead", "lean_post", "prolong_in_image")
+OPTS = ("swap_rp", "fold_x", "fold_prolong", "lazy_dead", "lean_post", "prolong_in_image", "fold_restrict")
 
 
 @pytest.mark.parametrize("plain", [0, 1])
@@ -183,6 +183,15 @@ def test_l6_vcycle_down_leg(case6, ctx, steps, plain):
         assert relerr(states[5].r.to_host(), st.r) <= 1e-10
         assert relerr(states[4].b.to_host(), nb) <= 1e-10
         assert not states[4].x.to_host().any()
+        if plain == 0:
+            # the restriction in the residual's epilogue (fold_restrict) against the stand-alone restriction kernel: the
+            # coarse right-hand side and the residual it is taken from are the same to the last bit
+            got_b, got_r = states[4].b.to_host(), states[5].r.to_host()
+            ctx.set_option("fold_restrict", 0)
+            states[5].x.from_host(x0); states[5].b.from_host(b0)
+            hmg.vcycle_down(c.g, [c.A] * 6, states, lev, steps)
+            np.testing.assert_array_equal(states[4].b.to_host(), got_b)
+            np.testing.assert_array_equal(states[5].r.to_host(), got_r)
     finally:
         for o in OPTS:
             ctx.set_option(o, 1)
@@ -191,7 +200,8 @@ def test_l6_vcycle_down_leg(case6, ctx, steps, plain):
 @pytest.mark.parametrize("plain", [0, 1, 2])
 def test_l6_vcycle_up_leg(case6, ctx, plain):
     """Second half: interpolate_and_sum_to!(curr.x, P, next.x), smoothing_steps! (src/multigrid.jl:112-115).  plain = 0:
-    the prolongation rides in the load phase of the post-smoother's first residual (parents gathered from global memory;
+    the prolongation rides in the load phase of the post-smoother's first residual (coarse column staged at the even nodes of
+    the LDS image;
     plain = 2: coarse column staged in LDS)."""
     c = case6
     O, lev, steps = c.O, 6, 3
