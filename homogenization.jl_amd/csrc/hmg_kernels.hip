@@ -1043,6 +1043,10 @@ __global__ void __launch_bounds__(256)
 k_iface_csr(const int32_t *__restrict__ eptr, const int32_t *__restrict__ eent, int64_t nedge, int nei, int off_edge,
             const int32_t *__restrict__ nptr, const int32_t *__restrict__ nent, int64_t nnode, int ld, double *x)
 {
+    // Copies are read in batches of U: all entries of a batch first, then all values (independent loads in flight together
+    // instead of one dependent entry -> value round trip per copy: a shared edge of the Kuhn lattice has 4 or 6 copies, a
+    // node 24), summed in list order as before.
+    constexpr int U = 8;
     const int64_t tedge = nedge * nei, total = tedge + nnode;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -1053,13 +1057,24 @@ k_iface_csr(const int32_t *__restrict__ eptr, const int32_t *__restrict__ eent, 
         const int32_t *ptr = is_edge ? eptr : nptr, *ent = is_edge ? eent : nent;
         const int b = ptr[e], end = ptr[e + 1];
         double s = 0.0;
-        for (int q = b; q < end; ++q) {
-            const int32_t v = ent[q];
-            s += x[(int64_t)(v >> 3) * ld + off + (v & 7) * per + k];
+        for (int q0 = b; q0 < end; q0 += U) {
+            int32_t v[U];
+            double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = q0 + u < end ? ent[q0 + u] : -1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = v[u] >= 0 ? x[(int64_t)(v[u] >> 3) * ld + off + (v[u] & 7) * per + k] : 0.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (v[u] >= 0) s += xv[u];
         }
-        for (int q = b; q < end; ++q) {
-            const int32_t v = ent[q];
-            x[(int64_t)(v >> 3) * ld + off + (v & 7) * per + k] = s;
+        for (int q0 = b; q0 < end; q0 += U) {
+            int32_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = q0 + u < end ? ent[q0 + u] : -1;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (v[u] >= 0) x[(int64_t)(v[u] >> 3) * ld + off + (v[u] & 7) * per + k] = s;
         }
     }
 }

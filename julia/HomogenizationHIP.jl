@@ -192,7 +192,14 @@ struct HipBaseLevel
     grid::HipGrid
     HipBaseLevel(g::HipGrid, A) = (bind!(g, A); check(ccall((:hmg_coarse_setup, LIB), Cint, (Ptr{Cvoid},), g.h)); new(g))
 end
-last_iterations(b::HipBaseLevel) = Int(ccall((:hmg_coarse_last_iterations, LIB), Cint, (Ptr{Cvoid},), b.grid.h))
+# iterations of the last level-1 solve (waits for it); an unconverged solve is an error, as it is for the call that
+# synchronises behind its V-cycle (include/hmg.h, hmg_coarse_last_iterations)
+function last_iterations(b::HipBaseLevel)
+    n = Int(ccall((:hmg_coarse_last_iterations, LIB), Cint, (Ptr{Cvoid},), b.grid.h))
+    n < 0 && error(unsafe_string(ccall((:hmg_last_error, LIB), Cstring, ())))
+    n
+end
+coarse_misses(b::HipBaseLevel) = Int(ccall((:hmg_coarse_misses, LIB), Int64, (Ptr{Cvoid},), b.grid.h))
 
 # fused fast path: one call per smoother / per V-cycle (src/multigrid.jl:46-119).  steps_coarse = 2 because the reference
 # does not forward `steps` to the recursive call (src/multigrid.jl:109).
