@@ -308,7 +308,8 @@ def main():
                          "kernel": ("hmg::k_apply<3,512,13,*,6> (finest-level operator apply, three 512-thread workgroups per CU"
                                     if L == 6 else "hmg::k_apply_slab<3,1024,*> (finest-level operator apply, rolling LDS window"
                                     if L == 7 else "hmg::k_apply (finest-level operator apply") +
-                                   "; per V-cycle: 1 residual, 6 fused CG passes, 2 residuals with the pending x-updates / the prolongation folded in)",
+                                   "; per V-cycle: 1 residual, 6 fused CG passes, the local residual with the pending x-updates and the restriction in its "
+                                   "epilogue, the residual with the coarse-grid correction staged in the LDS image)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
