@@ -146,6 +146,7 @@ struct hmg_ctx {
     bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
+    bool zero_entry = true;        // V-cycle: a coarse level's zero initial guess is never materialised (see vcycle_down())
     bool fold_restrict = true;     // V-cycle: the restriction rides in the epilogue of the local residual, which is then not stored
     bool prolong_in_image = true;  // folded prolongation, level 6: the coarse column is staged at the even nodes of the lattice image
                                    // instead of in LDS of its own behind it (three workgroups per CU stay resident)
@@ -1036,8 +1037,11 @@ struct DeferredX {
 // src/examples/homogenized_coefficients.jl:286), the next smoothing_steps! starts with p <- r and Ap <- 0.
 DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
                  bool live_tail = true, bool defer_x = false, bool swap_rp = false, const hmg_vec *xcoarse = nullptr,
-                 bool lazy = false, bool scratch_p = false)
+                 bool lazy = false, bool scratch_p = false, bool x_zero = false)
 {
+    // x_zero: x is the zero initial guess of a coarse level (src/multigrid.jl:106) and its memory does not hold the zeros:
+    // the first residual is r = b under the constraint (b - A 0 = b to the last bit), and the caller must not let anything
+    // read x before the deferred x-updates write it (vcycle_down checks that the step pattern guarantees this)
     DeferredX none;
     // ref: src/multigrid.jl:46-71
     const LevelDev &lv = lev(g, level);
@@ -1051,7 +1055,12 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
         a.src = b->d;
         a.out = r->d;
         a.flags = 1;
-        if (xcoarse) {
+        if (x_zero) {
+            need(!xcoarse, "zero initial guess with a coarse-grid correction");
+            launch_copy(L, r->d, b->d, n);
+            launch_mask(L, lv, g->md, r->d, 0);
+            interface_sum(g, lv, r->d);
+        } else if (xcoarse) {
             a.xcoarse = xcoarse->d;
             a.ldc = lev(g, level - 1).ld;
             a.xout = x->d;
@@ -1358,8 +1367,20 @@ void coarse_solve(hmg_grid *g, hmg_vec *b1, hmg_vec *x1)
 // zero initial guess on the coarser level.  Inside the library the pre-smoother's dead tail is dropped and its pending
 // x-update(s) ride in the load phase of the local residual (see smooth()); x, the local residual in r and the
 // coarse right-hand side are what the reference leaves, p and Ap are scratch.
-void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st, bool inside = false)
+// Can level k be entered with a zero initial guess that is never written to memory?  Level 1: the scatter of the coarse
+// solution overwrites every entry of x.  Levels above: with the default two CG steps and the lazy dead tail the pre-smoother
+// never touches x, and the local residual that carries both pending x-updates writes it (flags bit 7: x is not read).
+bool zero_entry_ok(const hmg_grid *g, int k, int steps)
 {
+    if (!g->ctx->zero_entry) return false;
+    if (k == 1) return true;
+    return g->fuse_cg && g->ctx->fold_x && g->ctx->lazy_dead && steps == 2;
+}
+
+void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st, bool inside = false, bool x_zero = false, int steps_next = -1)
+{
+    // x_zero: this level's x is a zero nobody has written (see zero_entry_ok); steps_next: the CG steps the next coarser
+    // level will take (inside hmg_vcycle; decides whether ITS zero initial guess has to be written)
     // inside (hmg_vcycle): nobody can read this level's r before the post-smoother's first residual overwrites it
     // (src/multigrid.jl:104-113), so where the apply kernel can restrict in its epilogue the cell-local residual is
     // never stored -- the coarse right-hand side is the same to the last bit (option fold_restrict)
@@ -1369,7 +1390,9 @@ void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st, bool inside = fals
     // (an odd number of pointer exchanges would leave r and p swapped: both smoother calls take the same `steps`)
     const bool swap_rp = g->ctx->swap_rp && g->fuse_cg && steps > 0;
     const DeferredX dx = smooth(g, k, steps, cur[0], cur[1], cur[2], cur[3], cur[4], /*live_tail=*/false,
-                                /*defer_x=*/g->ctx->fold_x, swap_rp, nullptr, /*lazy=*/g->ctx->lazy_dead);
+                                /*defer_x=*/g->ctx->fold_x, swap_rp, nullptr, /*lazy=*/g->ctx->lazy_dead, false, x_zero);
+    need(!x_zero || (dx.rs >= 0 && dx.two_updates), "zero initial guess: the pre-smoother did not defer both x-updates");
+    const bool skip_fill = inside && steps_next >= 0 && zero_entry_ok(g, k - 1, steps_next);
     if (dx.rs >= 0) {
         // local residual with the pre-smoother's pending x-update(s) folded into its load phase (x written back),
         // r = b - A x: 40 B/DOF instead of 24 + 24; in the lazy form the dead step wrote neither x nor p (16 B/DOF
@@ -1394,13 +1417,13 @@ void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st, bool inside = fals
         }
         a.src = cur[1]->d;
         a.out = cur[2]->d;
-        a.flags = 1;
+        a.flags = 1 | (x_zero ? 128 : 0);
         if (g->ctx->fold_restrict && apply_restricts(L, lev(g, k))) {
             if (inside) a.out = nullptr;          // (hmg_vcycle_down hands r back: there it is stored as well)
             a.rcoarse = nxt[1]->d;
             a.ldrc = lev(g, k - 1).ld;
             apply_then_sum(g, lev(g, k), a, true, -1, -1, /*sum_out=*/false);
-            launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
+            if (!skip_fill) launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
             return;
         }
         apply_then_sum(g, lev(g, k), a, true, -1, -1, /*sum_out=*/false);
@@ -1408,7 +1431,7 @@ void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st, bool inside = fals
         apply(g, lev(g, k), -1.0, cur[0]->d, cur[1]->d, cur[2]->d, 1);                        // local residual
     }
     restrict_level(g, k, cur[2]->d, nxt[1]->d);
-    launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
+    if (!skip_fill) launch_fill(L, nxt[0]->d, vec_len(nxt[0]), 0.0);
 }
 
 // Up leg (src/multigrid.jl:112-115): coarse-grid correction x_k += P x_{k-1}, post-smoother.
@@ -1441,7 +1464,8 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st, bool 
         coarse_solve(g, cur[1], cur[0]);
         return;
     }
-    vcycle_down(g, k, steps, st, /*inside=*/true);
+    // (below the top level x is the zero initial guess the level above left -- written only if this level needs it in memory)
+    vcycle_down(g, k, steps, st, /*inside=*/true, /*x_zero=*/!top && zero_entry_ok(g, k, steps), steps_coarse);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st, false);
     vcycle_up(g, k, steps, st, g->ctx->lean_post ? (top ? 1 : 2) : 0);
 }
@@ -1895,6 +1919,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->swap_rp = value != 0;
     else if (n == "fold_prolong")
         ctx->fold_prolong = value != 0;
+    else if (n == "zero_entry")
+        ctx->zero_entry = value != 0;
     else if (n == "fold_restrict")
         ctx->fold_restrict = value != 0;
     else if (n == "lazy_dead")

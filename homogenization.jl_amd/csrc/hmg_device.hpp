@@ -101,7 +101,8 @@ struct ApplyArgs {
     int flags;             // bit 0: Dirichlet constraint on out; bit 1: mass term only; bit 2 (slab kernel): weights =
                            // last term of the class table, no per-cell scaling (restriction); bit 3 (fused): src
                            // multiplies instead of being added, sum mult (x + src) out; bit 4: mass term not scaled
-                           // by |J|; bit 5 (fused): unit multiplicities
+                           // by |J|; bit 5 (fused): unit multiplicities; bit 6 (fused, xcoarse): the coarse column is staged
+                           // in the lattice image; bit 7 (fused, x3 mode): x is zero and is not read
     int64_t ncells_prefix; // > 0: only the first ncells_prefix cells
     int64_t out_ld;        // column stride of out if it differs from the level's (slab restriction), else 0
     const int32_t *cell_list;   // optional: workgroup b works on cell cell_list[b] (ncell_list of them)

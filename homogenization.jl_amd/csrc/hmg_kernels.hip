@@ -325,6 +325,9 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             }
         }
         constexpr int HB = FUSED ? (SPT + 1) / 2 : SPT;
+        // flags bit 7 (fused passes through the batch path below): x is known to be zero -- a coarse level entered with the zero
+        // initial guess of src/multigrid.jl:106 -- and is not read (its memory need not even hold the zeros yet)
+        const bool xzero = FUSED && (a.flags & 128);
         if (!light && !light2 && !(cgather && ccol)) {
 #pragma unroll
         for (int q0 = 0; q0 < SPT; q0 += HB) {
@@ -335,7 +338,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             for (int q = 0; q < HB; ++q) {
                 const int t = tid + (q0 + q) * NT;
                 if (q0 + q < SPT && t < nf) {
-                    xv[q] = xc[t];
+                    xv[q] = xzero ? 0.0 : xc[t];
                     x2v[q] = x2c ? x2c[t] : 0.0;
                     xav[q] = xac ? xac[t] : x3c ? x3c[t] : 0.0;
                     lp[q] = lv.lpos[t];
@@ -370,7 +373,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
         }
         for (int t = tid + SPT * NT; t < nf; t += NT) {   // only for cells larger than SPT*NT
-            double v = xc[t];
+            double v = xzero ? 0.0 : xc[t];
             if (FUSED) {
                 const double pv = x2c ? x2c[t] : 0.0;
                 if (!cgather && ccol) v = prolong(v, lv.par32[t]);
@@ -857,6 +860,8 @@ static void check_apply_bases(const ApplyArgs &a, const MeshDev &mesh)
     if (!mesh.coef) throw std::runtime_error("operator apply: no operator coefficients on the device (hmg_grid_set_operator)");
     if ((a.flags & 1) && !mesh.dmask) throw std::runtime_error("operator apply: constraint requested without a Dirichlet mask");
     if (a.xcoarse && !a.xout) throw std::runtime_error("operator apply: folded prolongation without xout");
+    if ((a.flags & 128) && !(FUSED && a.x3 && a.x2 && a.xout && !a.xcoarse))
+        throw std::runtime_error("operator apply: the zero-input form exists for the residual with two pending x-updates only");
 }
 
 template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false, bool CG = false, bool RS = false>

@@ -677,3 +677,41 @@ def test_handles_may_be_destroyed_in_any_order(oracle):
     a.close()
     assert hmg.dot(c, c) == 9.0 * n
     c.close()                                     # last reference: grid and context go now
+
+
+EXACT_OPTIONS = ("lean_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict",
+                 "zero_entry")
+
+
+@pytest.mark.parametrize("dim,n,levels", [(3, 4, 5), (3, 2, 6), (2, 8, 5)])
+def test_exact_savings_are_exact(ctx, dim, n, levels):
+    """Every saving hmg_vcycle takes that the reference's own control flow makes exact -- dead tails of both smoothers, r taken
+    as p by a handle exchange, prolongation folded into a residual (coarse column staged in the image on level 6), face sums
+    inside the r-update, restriction in the local residual's epilogue (level 6), coarse levels whose zero initial guess is
+    never written -- on and off: x and r of the finest level after three V-cycles are the same to the last bit
+    (src/multigrid.jl:46-119 is the plain sequence)."""
+    from homogenization_jl_amd import driver
+    tag = hmg.Tet64 if dim == 3 else hmg.Tri64
+    base, cond, g, op = driver.checkerboard_problem(ctx, tag, n, levels, seed=11)
+    res = []
+    try:
+        for on in (1, 0):
+            for o in EXACT_OPTIONS:
+                ctx.set_option(o, on)
+            st = [hmg.LevelState(g, i + 1) for i in range(levels)]
+            st[-1].x.rand(3); st[-1].b.rand(4)
+            hmg.broadcast_interfaces(st[-1].x, g, levels)
+            hmg.apply_constraint(st[-1].x, levels, g)
+            bl = hmg.BaseLevel(g)
+            for _ in range(3):
+                hmg.vcycle(g, bl, [op] * levels, st, levels, 3)
+            res.append((st[-1].x.to_host(), st[-1].r.to_host(), hmg.norm_unique(st[-1].r)))
+            for s in st:
+                s.close()
+    finally:
+        for o in EXACT_OPTIONS:
+            ctx.set_option(o, 1)
+        g.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2] and np.isfinite(res[0][2])
