@@ -174,7 +174,8 @@ struct hmg_ctx {
     // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
     // the work per rank, the message sizes and the stream choreography are the real ones, the numbers are not)
     bool comm_rehearsal = false;
-    int64_t overlap_min_doubles = 131072;   // exchanges below 1 MiB are not overlapped (see apply_then_sum)
+    int64_t overlap_min_doubles = 524288;   // levels whose GLOBAL cut is below 4 MiB (about 1 MiB per rank at octants) are
+                                            // exchanged in the plain form (see apply_then_sum)
     // grids of this context whose last budgeted level-1 solve still has its probe in flight: judged at the next call that
     // synchronises the stream anyway (norms, dot products, integrals, hmg_ctx_sync, downloads)
     std::vector<struct hmg_grid *> probe_grids;
@@ -940,12 +941,17 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
                            (a.xacc ? 2.0 : 0.0) + (a.x3 ? 1.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0) +
                            (a.rcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
-    const int64_t ncut = has_exchange(g) ? cut_doubles(g, lv) : 0;
     // (overlapping costs launches -- the apply in two parts, the interface sums in two parts: worth it where the exchange
     //  moves real data; on the small levels, launch-bound as they are, it only adds to the chain.  Rehearsal on one rank,
     //  profiles/r03_partitioned_overhead.txt: every level overlapped +3.6 ms per V-cycle, none +0.0.)
-    const bool overlap = g->part && (g->sharers ? g->p2p_begin != nullptr : g->ex_begin != nullptr) && g->ex_end && g->overlap &&
-                         ncut >= std::max<int64_t>(1, c->overlap_min_doubles) && g->md.ncells_cut > 0;
+    // The decision must be the SAME ON EVERY RANK: the overlapped form issues the exchange before the scalar sums, the plain
+    // form after them, and calls on one communicator have to come in one order everywhere.  So it looks at the global size of
+    // the cut on this level (identical on all ranks), never at what this rank happens to own; a rank without cut cells walks
+    // the overlapped form with empty lists.
+    const bool has_cut = has_exchange(g) && g->part && g->cut[0].nglobal + g->cut[1].nglobal + g->cut[2].nglobal > 0;
+    const int64_t global_cut = has_cut ? g->cut[0].nglobal * lv.nfi + g->cut[1].nglobal * lv.nei + g->cut[2].nglobal : 0;
+    const bool overlap = has_cut && (g->sharers ? g->p2p_begin != nullptr : g->ex_begin != nullptr) && g->ex_end && g->overlap &&
+                         global_cut >= std::max<int64_t>(1, c->overlap_min_doubles);
     auto launch = [&](const int32_t *list, int64_t n) {
         ApplyArgs b = a;
         b.cell_list = list;
@@ -991,7 +997,7 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
         interface_sum(g, lv, a.out, faces);
         return;
     }
-    launch(g->md.cells_cut, g->md.ncells_cut);
+    if (g->md.ncells_cut > 0) launch(g->md.cells_cut, g->md.ncells_cut);
     launch_interface_sum(L, lv, g->md, a.out, 1);        // local copies of the cut entities
     exchange_prepare(g, lv);
     cut_pack(g, lv, a.out, 0);

@@ -902,8 +902,13 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     // (level 4, 165 nodes: one wave per cell in three passes beats three waves -- 32 instead of 10 cells in flight per CU,
     //  V-cycle from level 4 down 11.26 -> 10.05 ms)
     if (nt == 0) nt = nf <= 192 ? 64 : nf <= 2048 ? 256 : 1024;
-    if (nt <= 64)
-        launch_apply_generic<DIM, 64, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
+    if (nt <= 64) {
+        // (level 4, 165 nodes per wave: three slots per lane loaded as batches, not one dependent round trip per slot)
+        if (nf > 64)
+            launch_apply_generic<DIM, 64, 3, FUSED, 0, WD>(L, lv, mesh, a, lds);
+        else
+            launch_apply_generic<DIM, 64, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
+    }
     else if (nt <= 192 && nf <= 192)
         launch_apply_generic<DIM, 192, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 256 && nf <= 1024) {

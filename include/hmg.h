@@ -206,8 +206,10 @@ int hmg_grid_set_exchange(hmg_grid *grid, hmg_exchange_fn exchange, hmg_exchange
  * apply / interface sums of the cells that do not touch a partition cut (hmg_grid_set_overlap, default on). */
 int hmg_grid_set_exchange_async(hmg_grid *grid, hmg_exchange_fn begin, int (*end)(void *user));
 int hmg_grid_set_overlap(hmg_grid *grid, int enabled);
-/* (context option "overlap_min_doubles", default 131072 = 1 MiB: exchanges smaller than that run in the synchronous form
- *  even with the overlap on -- splitting the launches of a launch-bound small level costs more than its message hides) */
+/* (context option "overlap_min_doubles", default 524288: levels whose GLOBAL cut -- one value per cut DOF, the same number
+ *  on every rank, so that all ranks decide alike and issue their collectives in one order -- is smaller than 4 MiB run in
+ *  the plain form even with the overlap on: splitting the launches of a launch-bound small level costs more than its
+ *  messages hide) */
 /* Exchange among the sharers only (SURVEY 8e's cheaper alternative; the default of hmg_grid_use_comm).  The library groups
  * the cut entities into SEGMENTS by the set of ranks that share them (octants: a quarter of a cut plane = 2 ranks, half an
  * axis line = 4, the centre node = 8), lays this rank's segments out one after the other in the exchange buffer (a segment
