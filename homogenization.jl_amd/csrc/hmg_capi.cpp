@@ -91,6 +91,7 @@ struct LevelBufs {
     DevBuf<uint16_t> clpos;
     DevBuf<uint32_t> rs_word;
     DevBuf<double> rs_w;
+    DevBuf<uint16_t> rs_lp;
     DevBuf<uint16_t> blk_slot;
     int nblk = 0, blk_R = 0;
     DevBuf<double> ctab;
@@ -745,6 +746,13 @@ static void upload_levels(hmg_grid *g)
                             T.ctab[((size_t)c * T.ndir + d) * T.nterm + T.nterm - 1] != 0.0 ? (d == 0 ? 1.0 : 0.5) : 0.0;
                 B.rs_word.upload(rw, s);
                 B.rs_w.upload(wts, s);
+                if (T.nf <= 2048) {
+                    // levels whose stand-alone restriction is k_restrict: the epilogue sums in ITS order (the reference's:
+                    // identity row first, then the midpoints in ascending fine hierarchical id) -- same bits on both paths
+                    std::vector<uint16_t> lp(T.ridx.size());
+                    for (size_t e = 0; e < lp.size(); ++e) lp[e] = (uint16_t)(T.meta[(size_t)T.ridx[e]] & 0xffffu);
+                    B.rs_lp.upload(lp, s);
+                }
             }
             B.rptr.upload(T.rptr, s);
             B.ridx.upload(T.ridx, s);
@@ -791,6 +799,7 @@ static void upload_levels(hmg_grid *g)
         D.clpos = B.clpos.p;
         D.rs_word = B.rs_word.p;
         D.rs_w = B.rs_w.p;
+        D.rs_lp = B.rs_lp.p;
         D.rptr = B.rptr.p;
         D.ridx = B.ridx.p;
         D.dphi = B.dphi.p;
@@ -1380,7 +1389,12 @@ bool zero_entry_ok(const hmg_grid *g, int k, int steps)
 {
     if (!g->ctx->zero_entry) return false;
     if (k == 1) return true;
-    return g->fuse_cg && g->ctx->fold_x && g->ctx->lazy_dead && steps == 2;
+    if (!(g->fuse_cg && g->ctx->fold_x && g->ctx->lazy_dead && steps == 2)) return false;
+    // (register-blocked levels take that residual through the instantiation that also restricts in its epilogue -- the only one
+    //  of theirs the zero-input form is compiled into)
+    const LevelDev &lv = g->ld[k - 1];
+    if (lv.blk_R > 0) return g->ctx->fold_restrict && apply_restricts(g->ctx->L, lv);
+    return true;
 }
 
 void vcycle_down(hmg_grid *g, int k, int steps, hmg_vec **st, bool inside = false, bool x_zero = false, int steps_next = -1)

@@ -42,6 +42,9 @@ struct LevelDev {
     // node (decode32w: i | j<<7 | k<<14 | cls<<21) and the weights 1 / 0.5 / 0 of the 15 taps per entity class
     const uint32_t *rs_word;       // [nf_coarse]
     const double *rs_w;            // [ncls * ndir]
+    // ... or, on levels whose stand-alone restriction is k_restrict (summation in the reference's order: ascending fine
+    // hierarchical id), the same lists with lattice positions in place of storage slots: entry e of ridx -> rs_lp[e]
+    const uint16_t *rs_lp;         // [size of ridx] or null (levels restricted by the slab kernel: stencil order above)
     const int32_t *rptr, *ridx;    // [nf_coarse+1], [..] (level > 1)
     const double *dphi;            // [3*nf]
 };

@@ -327,7 +327,9 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         constexpr int HB = FUSED ? (SPT + 1) / 2 : SPT;
         // flags bit 7 (fused passes through the batch path below): x is known to be zero -- a coarse level entered with the zero
         // initial guess of src/multigrid.jl:106 -- and is not read (its memory need not even hold the zeros yet)
-        const bool xzero = FUSED && (a.flags & 128);
+        // (compiled into the instantiations that can meet it only -- the local residual of a register-blocked level is the RS
+        //  one -- : in the main fused instantiation the extra live value cost three spilled registers)
+        const bool xzero = FUSED && (RS || RB == 0) && (a.flags & 128);
         if (!light && !light2 && !(cgather && ccol)) {
 #pragma unroll
         for (int q0 = 0; q0 < SPT; q0 += HB) {
@@ -568,6 +570,21 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
         __syncthreads();
         double *rc = a.rcoarse + cell * a.ldrc;
+        if (lv.rs_lp) {
+            // (levels whose stand-alone restriction is k_restrict: its order -- the reference's -- and its roundings)
+            for (int c = tid; c < lv.nf_coarse; c += NT) {
+                const int b = lv.rptr[c], n = lv.rptr[c + 1] - b;
+                int lp[15];
+#pragma unroll
+                for (int q = 0; q < 15; ++q) lp[q] = lv.rs_lp[b + (q < n ? q : 0)];
+                double tmp = 0.0;
+                tmp += 1.0 * lds_ld(xs + lp[0]);
+#pragma unroll
+                for (int q = 1; q < 15; ++q)
+                    if (q < n) tmp += 0.5 * lds_ld(xs + lp[q]);
+                rc[c] = tmp;
+            }
+        } else
         for (int c = tid; c < lv.nf_coarse; c += NT) {
             int L, len, A, B, cls, k;
             decode32w(lv.rs_word[c], m, L, len, A, B, cls, k);
@@ -837,9 +854,13 @@ size_t apply_lds_bytes(const LevelDev &lv)
 bool apply_restricts(const Launch &L, const LevelDev &lv)
 {
     // the conditions under which launch_apply_dim reaches the 512-thread register-blocked instantiations (level 6)
-    return lv.dim == 3 && apply_lds_bytes(lv) <= 160 * 1024 && L.apply_threads == 0 && lv.nf > 2048 && lv.blk_R == 6 &&
-           lv.nblk <= 960 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 && !L.apply_unblocked && L.apply_wg512 &&
-           lv.nfi <= 512 && lv.rs_word && lv.rs_w && lv.nf_coarse > 0;
+    if (!(lv.dim == 3 && apply_lds_bytes(lv) <= 160 * 1024 && L.apply_threads == 0 && !L.apply_unblocked && lv.rs_word &&
+          lv.rs_w && lv.nf_coarse > 0 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4))
+        return false;
+    if (lv.nf > 2048)       // level 6: the 512-thread shape
+        return lv.blk_R == 6 && lv.nblk <= 960 && L.apply_wg512 && lv.nfi <= 512;
+    // level 5: the 256-thread shape (its stand-alone restriction is k_restrict: the epilogue needs that kernel's lists)
+    return lv.nf > 192 && lv.nf <= 1024 && lv.blk_R == 4 && lv.nblk <= 192 && lv.nfi <= 128 && lv.rs_lp != nullptr;
 }
 
 static size_t apply_lds_bytes_rb(const LevelDev &lv)   // register-blocked instantiations: only the corners' weight rows in LDS
@@ -869,6 +890,8 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
 {
     auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD, CG, RS>;
     if (a.rcoarse && !RS) throw std::runtime_error("operator apply: this instantiation cannot restrict in its epilogue");
+    if ((a.flags & 128) && !(FUSED && (RS || RB == 0)))
+        throw std::runtime_error("operator apply: this instantiation cannot take a zero input that is not in memory");
     if (FUSED && a.xcoarse && !CG) lds += sizeof(double) * (size_t)lv.nf_coarse;   // coarse column behind the lattice image
     if (lds > 48 * 1024)
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -913,8 +936,16 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         launch_apply_generic<DIM, 192, 1, FUSED, 0, WD>(L, lv, mesh, a, lds);
     else if (nt <= 256 && nf <= 1024) {
         if (DIM == 3 && lv.blk_R == 4 && lv.nblk <= 192 && lv.nfi <= 128 && lv.nei <= 64 && lv.nedge == 6 && lv.ncorner == 4 &&
-            !L.apply_unblocked)
+            !L.apply_unblocked) {
+            if constexpr (!WD) {
+                if (FUSED && DIM == 3 && a.rcoarse && lv.rs_word && lv.rs_w && !a.xcoarse) {
+                    launch_apply_generic<DIM, 256, 4, FUSED, DIM == 3 ? 4 : 0, false, false, FUSED && DIM == 3>(
+                        L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                    return;
+                }
+            }
             launch_apply_generic<DIM, 256, 4, FUSED, DIM == 3 ? 4 : 0, WD>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+        }
         else
             launch_apply_generic<DIM, 256, 4, FUSED, 0, WD>(L, lv, mesh, a, lds);
     }
