@@ -18,6 +18,8 @@ ap.add_argument("--burst", type=int, default=3)
 ap.add_argument("--levels", type=int, default=6)
 ap.add_argument("--width", type=int, default=32)
 args = ap.parse_args()
+keys = [sorted(kv.split("=")[0] for kv in o.split(",") if kv) for o in args.sets]
+assert all(k == keys[0] for k in keys), "every option set must assign the same keys (the switches persist from one burst to the next)"
 ctx = hmg.Context(0)
 L = args.levels
 base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, args.width, L, seed=0)
