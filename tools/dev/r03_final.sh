@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round 3, final GPU call: whole GPU suite, smoke(), the default bench line, a 2-rank rehearsal of bench.py's N > 1 path over gloo, profiles.
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r03final; rm -rf $O; mkdir -p $O
+cd $R
+step() {  # step <seconds> <name> <cmd...>
+    local t=$1 n=$2; shift 2
+    echo "== $n" | tee -a $O/steps.log
+    timeout -k 10 $t "$@" > $O/$n.log 2> $O/$n.err
+    local rc=$?
+    echo "   rc=$rc" | tee -a $O/steps.log
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $n: stopping" | tee -a $O/steps.log; exit 1; fi
+    return 0
+}
+step 1100 tests_all python3 -m pytest tests -q -m gpu
+tail -n 4 $O/tests_all.log
+step 300 smoke python3 __graft_entry__.py smoke
+tail -n 2 $O/smoke.log
+step 600 bench_default python3 bench.py
+cut -c1-600 $O/bench_default.log
+HMG_SINGLE_DEVICE=1 HMG_DIST_BACKEND=gloo step 600 bench_2rank_gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --width 8 --levels 5 --steps 3 --warmup 1 --no-cpu-baseline --no-time-to-tolerance
+cut -c1-400 $O/bench_2rank_gloo.log
+HMG_REHEARSE_WORLD=8 step 600 part_r8_overlap python3 bench.py --no-cpu-baseline --no-time-to-tolerance --steps 10 --warmup 2
+HMG_SYNTHETIC_CUT=planes step 600 part_syn_overlap python3 bench.py --no-cpu-baseline --no-time-to-tolerance --steps 10 --warmup 2
+step 300 bench_l7 python3 bench.py --levels 7 --width 16 --sigma-high 100 --no-cpu-baseline --no-time-to-tolerance --steps 5 --warmup 2
+grep -h '"metric"' $O/bench_default.log $O/part_*.log $O/bench_l7.log | python3 -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print(round(d['ms_per_step'],2), '%.3e' % d['value'], round(d['roofline']['avg_launch_ms'],3), round(d['roofline']['frac'],3), d['config']['residual_norm_after'], d['config']['workload'][:90])
+" | tee $O/summary.txt
+bash $R/tools/collect_profiles.sh r03 > $O/collect.log 2>&1 && bash $R/tools/dev/apply_sequence.sh > $O/sequence.log 2>&1
+echo done
