@@ -171,6 +171,10 @@ struct hmg_ctx {
     // 0.001 s fresh, 2.05 s after a hipFree), i.e. 1.9 s of the 71 GB a second driver call allocates.
     bool vec_pool_on = true;
     std::vector<std::pair<size_t, void *>> vec_pool;
+    // experiment (HMG_VEC_ARENA_GB): level vectors are carved out of ONE device allocation made at the first request
+    char *arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    bool in_arena(const void *p) const { return arena && (const char *)p >= arena && (const char *)p < arena + arena_cap; }
     // rehearsal on fewer GPUs than the partition is meant for: a grid that holds rank r's share of an N-rank partition
     // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
     // the work per rank, the message sizes and the stream choreography are the real ones, the numbers are not)
@@ -189,8 +193,14 @@ void vec_pool_trim(hmg_ctx *c)
     LifetimeLock lock(lifetime_mutex());
     if (c->vec_pool.empty()) return;
     (void)hipStreamSynchronize(c->stream);
-    for (auto &b : c->vec_pool) (void)hipFree(b.second);
-    c->vec_pool.clear();
+    std::vector<std::pair<size_t, void *>> keep;
+    for (auto &b : c->vec_pool) {
+        if (c->in_arena(b.second))
+            keep.push_back(b);                   // (arena blocks go with the arena)
+        else
+            (void)hipFree(b.second);
+    }
+    c->vec_pool.swap(keep);
 }
 
 std::vector<hmg_ctx *> &live_contexts()
@@ -218,6 +228,26 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
             c->vec_pool.pop_back();
             break;
         }
+    if (!p && !c->arena) {
+        if (const char *e = std::getenv("HMG_VEC_ARENA_GB")) {
+            const size_t cap = (size_t)std::atoll(e) << 30;
+            void *a = nullptr;
+            if (cap > 0 && hipMalloc(&a, cap) == hipSuccess) {
+                c->arena = (char *)a;
+                c->arena_cap = cap;
+                c->arena_used = 0;
+            } else
+                (void)hipGetLastError();
+        }
+    }
+    if (!p && c->arena) {
+        const size_t al = (size_t)2 << 20;
+        const size_t start = (c->arena_used + al - 1) / al * al;
+        if (start + bytes <= c->arena_cap) {
+            p = c->arena + start;
+            c->arena_used = start + bytes;
+        }
+    }
     if (!p && hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
         release_pooled_memory();                 // pooled blocks of other sizes (any context's) may be what is in the way
@@ -242,6 +272,10 @@ void vec_release(hmg_ctx *c, void *p, size_t bytes)
         return;
     }
     (void)hipStreamSynchronize(c->stream);
+    if (c->in_arena(p)) {
+        c->vec_pool.emplace_back(bytes, p);      // (cannot be freed on its own)
+        return;
+    }
     (void)hipFree(p);
 }
 
@@ -1810,6 +1844,7 @@ static void ctx_unref(hmg_ctx *ctx)
         (void)hipEventDestroy(ev.second);
     }
     vec_pool_trim(ctx);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->comm) (void)rccl().CommDestroy(ctx->comm);
     if (ctx->ev_packed) (void)hipEventDestroy(ctx->ev_packed);
     if (ctx->ev_summed) (void)hipEventDestroy(ctx->ev_summed);
