@@ -174,6 +174,7 @@ struct hmg_ctx {
     // experiment (HMG_VEC_ARENA_GB): level vectors are carved out of ONE device allocation made at the first request
     char *arena = nullptr;
     size_t arena_cap = 0, arena_used = 0;
+    int arena_blocks = 0;
     bool in_arena(const void *p) const { return arena && (const char *)p >= arena && (const char *)p < arena + arena_cap; }
     // rehearsal on fewer GPUs than the partition is meant for: a grid that holds rank r's share of an N-rank partition
     // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
@@ -242,7 +243,12 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
     }
     if (!p && c->arena) {
         const size_t al = (size_t)2 << 20;
-        const size_t start = (c->arena_used + al - 1) / al * al;
+        size_t start = (c->arena_used + al - 1) / al * al;
+        if (const char *e = std::getenv("HMG_VEC_ARENA_STAGGER_KB")) {   // experiment: the n-th block starts n x this further on
+            start += (size_t)c->arena_blocks * ((size_t)std::atoll(e) << 10);
+            start = (start + 255) / 256 * 256;
+        }
+        c->arena_blocks += 1;
         if (start + bytes <= c->arena_cap) {
             p = c->arena + start;
             c->arena_used = start + bytes;
