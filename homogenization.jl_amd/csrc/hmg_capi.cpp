@@ -174,7 +174,7 @@ struct hmg_ctx {
     // experiment (HMG_VEC_ARENA_GB): level vectors are carved out of ONE device allocation made at the first request
     char *arena = nullptr;
     size_t arena_cap = 0, arena_used = 0;
-    int arena_blocks = 0;
+    int arena_blocks = 0, arena_big = 0;
     bool in_arena(const void *p) const { return arena && (const char *)p >= arena && (const char *)p < arena + arena_cap; }
     // rehearsal on fewer GPUs than the partition is meant for: a grid that holds rank r's share of an N-rank partition
     // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
@@ -244,11 +244,29 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
     if (!p && c->arena) {
         const size_t al = (size_t)2 << 20;
         size_t start = (c->arena_used + al - 1) / al * al;
-        if (const char *e = std::getenv("HMG_VEC_ARENA_STAGGER_KB")) {   // experiment: the n-th block starts n x this further on
-            start += (size_t)c->arena_blocks * ((size_t)std::atoll(e) << 10);
-            start = (start + 255) / 256 * 256;
+        const char *sp = std::getenv("HMG_VEC_ARENA_SPACING_LOG2");
+        if (sp && bytes >= ((size_t)8 << 30)) {
+            // experiment: the big blocks at n x 2^k + n x stagger from the arena's start (learns which address bits matter);
+            // everything else is packed behind 6 x 2^k
+            const size_t k = (size_t)std::atoll(sp);
+            const char *e = std::getenv("HMG_VEC_ARENA_STAGGER_KB");
+            const size_t stg = e ? ((size_t)std::atoll(e) << 10) : 0;
+            start = (size_t)c->arena_big * (((size_t)1 << k) + stg);
+            c->arena_big += 1;
+            if (start + bytes <= c->arena_cap) {
+                p = c->arena + start;
+                start = c->arena_cap;             // (skip the bump allocation below)
+            }
+        } else {
+            if (sp && c->arena_used < 6 * ((size_t)1 << std::atoll(sp))) c->arena_used = 6 * ((size_t)1 << std::atoll(sp)), start = c->arena_used;
+            if (const char *e = std::getenv("HMG_VEC_ARENA_STAGGER_KB"); e && !sp) {   // experiment: the n-th block starts n x this further on
+                start += (size_t)c->arena_blocks * ((size_t)std::atoll(e) << 10);
+                start = (start + 255) / 256 * 256;
+            }
+            c->arena_blocks += 1;
         }
-        c->arena_blocks += 1;
+        if (p) {
+        } else
         if (start + bytes <= c->arena_cap) {
             p = c->arena + start;
             c->arena_used = start + bytes;
