@@ -171,11 +171,6 @@ struct hmg_ctx {
     // 0.001 s fresh, 2.05 s after a hipFree), i.e. 1.9 s of the 71 GB a second driver call allocates.
     bool vec_pool_on = true;
     std::vector<std::pair<size_t, void *>> vec_pool;
-    // experiment (HMG_VEC_ARENA_GB): level vectors are carved out of ONE device allocation made at the first request
-    char *arena = nullptr;
-    size_t arena_cap = 0, arena_used = 0;
-    int arena_blocks = 0, arena_big = 0;
-    bool in_arena(const void *p) const { return arena && (const char *)p >= arena && (const char *)p < arena + arena_cap; }
     // rehearsal on fewer GPUs than the partition is meant for: a grid that holds rank r's share of an N-rank partition
     // may use a communicator of another size (the neighbours' contributions are then simply missing from the sums --
     // the work per rank, the message sizes and the stream choreography are the real ones, the numbers are not)
@@ -194,14 +189,8 @@ void vec_pool_trim(hmg_ctx *c)
     LifetimeLock lock(lifetime_mutex());
     if (c->vec_pool.empty()) return;
     (void)hipStreamSynchronize(c->stream);
-    std::vector<std::pair<size_t, void *>> keep;
-    for (auto &b : c->vec_pool) {
-        if (c->in_arena(b.second))
-            keep.push_back(b);                   // (arena blocks go with the arena)
-        else
-            (void)hipFree(b.second);
-    }
-    c->vec_pool.swap(keep);
+    for (auto &b : c->vec_pool) (void)hipFree(b.second);
+    c->vec_pool.clear();
 }
 
 std::vector<hmg_ctx *> &live_contexts()
@@ -229,49 +218,6 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
             c->vec_pool.pop_back();
             break;
         }
-    if (!p && !c->arena) {
-        if (const char *e = std::getenv("HMG_VEC_ARENA_GB")) {
-            const size_t cap = (size_t)std::atoll(e) << 30;
-            void *a = nullptr;
-            if (cap > 0 && hipMalloc(&a, cap) == hipSuccess) {
-                c->arena = (char *)a;
-                c->arena_cap = cap;
-                c->arena_used = 0;
-            } else
-                (void)hipGetLastError();
-        }
-    }
-    if (!p && c->arena) {
-        const size_t al = (size_t)2 << 20;
-        size_t start = (c->arena_used + al - 1) / al * al;
-        const char *sp = std::getenv("HMG_VEC_ARENA_SPACING_LOG2");
-        if (sp && bytes >= ((size_t)8 << 30)) {
-            // experiment: the big blocks at n x 2^k + n x stagger from the arena's start (learns which address bits matter);
-            // everything else is packed behind 6 x 2^k
-            const size_t k = (size_t)std::atoll(sp);
-            const char *e = std::getenv("HMG_VEC_ARENA_STAGGER_KB");
-            const size_t stg = e ? ((size_t)std::atoll(e) << 10) : 0;
-            start = (size_t)c->arena_big * (((size_t)1 << k) + stg);
-            c->arena_big += 1;
-            if (start + bytes <= c->arena_cap) {
-                p = c->arena + start;
-                start = c->arena_cap;             // (skip the bump allocation below)
-            }
-        } else {
-            if (sp && c->arena_used < 6 * ((size_t)1 << std::atoll(sp))) c->arena_used = 6 * ((size_t)1 << std::atoll(sp)), start = c->arena_used;
-            if (const char *e = std::getenv("HMG_VEC_ARENA_STAGGER_KB"); e && !sp) {   // experiment: the n-th block starts n x this further on
-                start += (size_t)c->arena_blocks * ((size_t)std::atoll(e) << 10);
-                start = (start + 255) / 256 * 256;
-            }
-            c->arena_blocks += 1;
-        }
-        if (p) {
-        } else
-        if (start + bytes <= c->arena_cap) {
-            p = c->arena + start;
-            c->arena_used = start + bytes;
-        }
-    }
     if (!p && hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
         release_pooled_memory();                 // pooled blocks of other sizes (any context's) may be what is in the way
@@ -296,10 +242,6 @@ void vec_release(hmg_ctx *c, void *p, size_t bytes)
         return;
     }
     (void)hipStreamSynchronize(c->stream);
-    if (c->in_arena(p)) {
-        c->vec_pool.emplace_back(bytes, p);      // (cannot be freed on its own)
-        return;
-    }
     (void)hipFree(p);
 }
 
@@ -1868,7 +1810,6 @@ static void ctx_unref(hmg_ctx *ctx)
         (void)hipEventDestroy(ev.second);
     }
     vec_pool_trim(ctx);
-    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->comm) (void)rccl().CommDestroy(ctx->comm);
     if (ctx->ev_packed) (void)hipEventDestroy(ctx->ev_packed);
     if (ctx->ev_summed) (void)hipEventDestroy(ctx->ev_summed);
