@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 3, final GPU call: whole GPU suite, smoke(), the default bench line, a 2-rank rehearsal of bench.py's N > 1 path over gloo, profiles.
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r03final; rm -rf $O; mkdir -p $O
+# One GPU call that validates a build (used at the end of round 3): whole GPU suite, smoke(), the default bench line, a 2-rank rehearsal of bench.py's N > 1 path over gloo, profiles.
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/validate; rm -rf $O; mkdir -p $O
 cd $R
 step() {  # step <seconds> <name> <cmd...>
     local t=$1 n=$2; shift 2
