@@ -1251,13 +1251,25 @@ void coarse_pcg(hmg_grid *g)
     const double rtol2 = c->coarse_rtol * c->coarse_rtol;
     launch_coarse_init(L, A, g->c_b.p, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p);
     int slot_old = S_C0, slot_new = S_C3;          // r.z of the current / next iteration
+    // One iteration = two launches (k_coarse_direction, k_coarse_update; three until round 3).  The direction launch of
+    // iteration j does the bookkeeping of update j-1 (beta, convergence flag, count); a batch ends with a bookkeeping-only
+    // launch so that the flag and the count the host (or the probe) reads are those of its last update.
+    bool first = true, counted = true;
     auto iterate = [&](int count) {
         for (int q = 0; q < count; ++q) {
-            launch_coarse_spmv_dot(L, A, g->c_p.p, g->c_q.p);
+            if (first)
+                launch_coarse_direction(L, A, g->c_p.p, g->c_q.p, g->c_z.p, slot_old, slot_new, rtol2, 1, 0);
+            else {
+                launch_coarse_direction(L, A, g->c_p.p, g->c_q.p, g->c_z.p, slot_old, slot_new, rtol2, 0, counted ? 0 : 1);
+                std::swap(slot_old, slot_new);     // (the launch has published the new r.z in the other slot)
+            }
+            first = false;
             launch_coarse_update(L, A, g->c_x.p, g->c_r.p, g->c_z.p, g->c_p.p, g->c_q.p, slot_old);
-            launch_coarse_pupdate(L, A, g->c_p.p, g->c_z.p, slot_old, slot_new, rtol2);
-            std::swap(slot_old, slot_new);
+            counted = false;
         }
+        // bookkeeping of the batch's last update (leaves the slots alone: the next regular launch publishes the same value again)
+        launch_coarse_direction(L, A, g->c_p.p, g->c_q.p, g->c_z.p, slot_old, slot_new, rtol2, 2, 1);
+        counted = true;
     };
     auto probe = [&]() {
         HIPCHK(hipMemcpyAsync(pr.h, L.scal + S_DONE, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

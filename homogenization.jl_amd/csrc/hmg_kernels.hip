@@ -1913,36 +1913,69 @@ k_coarse_init(CoarseDev A, const double *__restrict__ b, double *x, double *r, d
     }
 }
 
+// Two-launch form of one PCG iteration (round 3): `direction` + `update`.  With q = A p carried by its own recurrence,
+//   p' = z + beta p,   q' = A z + beta q      (A p' = A z + beta A p),
+// the sparse product reads z, which the previous update left complete, and never a neighbour's p -- so the p-update, the
+// product and the partial sums of p.q are one kernel; beta, the convergence test and the bookkeeping that k_coarse_pupdate did
+// ride in its head (every block sums the same partials in the same order: the decision is the same in all of them).  On the
+// level-1 systems of configs 3-5 the recurrence changes neither the iteration count nor the true residual (7.7e-14 / 9.2e-14
+// at contrast 9 / 100, x equal to 5e-16): tools/dev note in profiles/r03_experiments.txt.
+//   mode 0: a regular iteration;  1: the first of a solve (p = z and rz come from k_coarse_init: q = A z);
+//   2: bookkeeping only (behind the last update of a batch, so that the host finds the flag and the count up to date)
+//   count_it = 0: the update before this launch has been counted already (by a mode-2 launch)
 __global__ void __launch_bounds__(256)
-k_coarse_spmv_dot(CoarseDev A, const double *__restrict__ p, double *q, double *partials, const double *__restrict__ scal)
+k_coarse_direction(CoarseDev A, double *p, double *q, const double *__restrict__ z, double *scal, int slot_old, int slot_new,
+                   const double *__restrict__ part_rz, const double *__restrict__ part_rr, int nb_upd, double rtol2, int mode,
+                   int count_it, double *part_pq)
 {
     __shared__ double red[4];
-    if (scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0)) return;   // converged (or b == 0: x stays 0): a no-op from here on
-    // 16 lanes per row (the level-1 matrix of the Freudenthal lattice has <= 15 entries per row): the lanes of a row
-    // read consecutive (value, column) pairs -- coalesced, where one thread per row strides by the row length -- and fold
-    // their products in a fixed xor tree, so the result does not depend on the launch shape.  Level-1 solve of 64^3 cubes
-    // (274 625 rows, 107 iterations, BASELINE config 4 -- every rank solves the whole system): 11.3 -> 4.9 ms.
+    __shared__ double bc;
+    __shared__ int skip;
+    if (threadIdx.x == 0) skip = scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0);
+    __syncthreads();
+    if (skip) return;
+    double beta = 0.0;
+    if (mode != 1) {
+        const double rz_new = sum_partials_all(part_rz, nb_upd, red, &bc);
+        const double rr = sum_partials_all(part_rr, nb_upd, red, &bc);
+        const double rz_old = scal[slot_old];
+        beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;
+        const bool done = rr <= rtol2 * scal[S_C2];                 // (NaN compares false: the budget runs out, the host sees S_CRR)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal[slot_new] = rz_new;
+            if (count_it) scal[S_ITER] += 1.0;
+            scal[S_CRR] = rr;
+            if (done) scal[S_DONE] = 1.0;
+        }
+        if (done || mode == 2) return;
+    }
+    // 16 lanes per row (the level-1 matrix of the Freudenthal lattice has <= 15 entries per row): the lanes of a row read
+    // consecutive (value, column) pairs -- coalesced, where one thread per row strides by the row length -- and fold their
+    // products in a fixed xor tree, so the result does not depend on the launch shape (64^3 cubes, 274 625 rows: 11.3 -> 4.9 ms
+    // per solve in round 2)
     const int sub = threadIdx.x & 15;
     double acc = 0.0;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < A.n; i += ((int64_t)gridDim.x * blockDim.x) >> 4) {
         const int b = A.rowptr[i], e = A.rowptr[i + 1];
         double s = 0.0;
-        for (int k = b + sub; k < e; k += 16) s += A.val[k] * p[A.colidx[k]];
+        for (int k = b + sub; k < e; k += 16) s += A.val[k] * z[A.colidx[k]];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
         if (sub == 0) {
-            q[i] = s;
-            acc += p[i] * s;
+            const double pi = mode == 1 ? z[i] : z[i] + beta * p[i];
+            const double qi = mode == 1 ? s : s + beta * q[i];
+            p[i] = pi;
+            q[i] = qi;
+            acc += pi * qi;
         }
     }
-    double s = block_sum(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    const double sacc = block_sum(acc, red);
+    if (threadIdx.x == 0) part_pq[blockIdx.x] = sacc;
 }
 
-// One PCG iteration = 3 launches: spmv_dot (partials of p.Ap -> P0), update (sums P0 itself; partials of r.z -> P1,
-// r.r -> P2), pupdate (sums P1 itself, stores the new r.z in the other of two scalar slots).  rz lives in
-// scal[slot_old] / scal[slot_new], exchanged by the host every iteration, so no kernel overwrites a scalar that
-// another block of the same launch may still read.
+// update: sums the partials of p.q itself (P0); partials of r.z -> P1, r.r -> P2.  rz lives in scal[slot_old] /
+// scal[slot_new], exchanged by the host every iteration, so no kernel overwrites a scalar that another block of the same
+// launch may still read.
 __global__ void __launch_bounds__(256)
 k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__restrict__ p, const double *__restrict__ q,
                 const double *__restrict__ scal, int slot_old, const double *__restrict__ part_pap, int nb, double *part_rz,
@@ -1969,33 +2002,6 @@ k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__re
     if (threadIdx.x == 0) {
         part_rz[blockIdx.x] = s0;
         part_rr[blockIdx.x] = s1;
-    }
-}
-
-// beta = rz_new / rz_old; p = z + beta p; block 0 publishes rz_new in scal[slot_new]
-__global__ void __launch_bounds__(256)
-k_coarse_pupdate(CoarseDev A, double *p, const double *__restrict__ z, double *scal, int slot_old, int slot_new,
-                 const double *__restrict__ part_rz, const double *__restrict__ part_rr, int nb, double rtol2)
-{
-    __shared__ double red[4];
-    __shared__ double bc;
-    // (block 0 sets the flag at the end of THIS launch, possibly while another block starts: one thread reads it for
-    //  its block, so the early return is block-uniform; a block that still sees 0 does one more harmless p-update)
-    __shared__ int skip;
-    if (threadIdx.x == 0) skip = scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0);
-    __syncthreads();
-    if (skip) return;
-    const double rz_new = sum_partials_all(part_rz, nb, red, &bc);
-    const double rr = sum_partials_all(part_rr, nb, red, &bc);
-    const double rz_old = scal[slot_old];
-    const double beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = z[i] + beta * p[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        scal[slot_new] = rz_new;
-        scal[S_ITER] += 1.0;
-        scal[S_CRR] = rr;
-        if (rr <= rtol2 * scal[S_C2]) scal[S_DONE] = 1.0;     // (NaN compares false: the budget runs out, the host sees S_CRR)
     }
 }
 
@@ -2038,27 +2044,22 @@ void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, do
     HMG_HIP_CHECK(hipMemsetAsync(L.scal + S_DONE, 0, 3 * sizeof(double), L.stream));   // S_DONE, S_ITER, S_CRR
     check_launch();
 }
-// partial buffers of the PCG inside L.partials (>= 4096 doubles, nb <= 1024): P0 p.Ap, P1 r.z, P2 r.r
-void launch_coarse_spmv_dot(const Launch &L, const CoarseDev &A, const double *p, double *q)
+// partial buffers of the PCG inside L.partials (>= 4096 doubles, nb <= 1024): P0 p.q, P1 r.z, P2 r.r
+void launch_coarse_direction(const Launch &L, const CoarseDev &A, double *p, double *q, const double *z, int slot_old, int slot_new,
+                             double rtol2, int mode, int count_it)
 {
-    int nb = coarse_spmv_blocks(A.n);
-    hipLaunchKernelGGL(k_coarse_spmv_dot, dim3(nb), dim3(256), 0, L.stream, A, p, q, L.partials, L.scal);
+    const int nb = mode == 2 ? 1 : coarse_spmv_blocks(A.n);
+    hipLaunchKernelGGL(k_coarse_direction, dim3(nb), dim3(256), 0, L.stream, A, p, q, z, L.scal, slot_old, slot_new,
+                       L.partials + 1024, L.partials + 2048, coarse_blocks(L, A.n), rtol2, mode, count_it, L.partials);
     check_launch();
 }
+
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
                           const double *q, int slot_old)
 {
     int nb = coarse_blocks(L, A.n);
     hipLaunchKernelGGL(k_coarse_update, dim3(nb), dim3(256), 0, L.stream, A, x, r, z, p, q, L.scal, slot_old, L.partials,
                        coarse_spmv_blocks(A.n), L.partials + 1024, L.partials + 2048);
-    check_launch();
-}
-void launch_coarse_pupdate(const Launch &L, const CoarseDev &A, double *p, const double *z, int slot_old, int slot_new,
-                           double rtol2)
-{
-    int nb = coarse_blocks(L, A.n);
-    hipLaunchKernelGGL(k_coarse_pupdate, dim3(nb), dim3(256), 0, L.stream, A, p, z, L.scal, slot_old, slot_new,
-                       L.partials + 1024, L.partials + 2048, nb, rtol2);
     check_launch();
 }
 // r.r of the last update -> scal[S_TMP] (convergence check)
