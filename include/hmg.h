@@ -63,7 +63,13 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * reference's own callers: the next smoothing_steps! overwrites them before reading, src/multigrid.jl:46-50;
  * 0 = they hold what the reference leaves), "prolong_in_image" (1 = default: on level 6 the folded prolongation stages the
  * coarse column at the even nodes of the LDS lattice image itself instead of in LDS of its own behind it, which would cost
- * the third resident workgroup; "prolong_gather", the option's round-2 name, is still accepted), "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
+ * the third resident workgroup; "prolong_gather", the option's round-2 name, is still accepted), "fold_restrict" (1 = default:
+ * inside hmg_vcycle the local residual of levels 6 and 5 restricts itself in its kernel's epilogue and is not stored; the
+ * coarse right-hand side is the stand-alone restriction's to the last bit), "zero_entry" (1 = default: inside hmg_vcycle a
+ * coarse level's zero initial guess is never written -- its first residual is the constrained copy of b and the local
+ * residual that carries both pending x-updates does not read x), "fold_faces" (1 = default: the face part of A p's
+ * interface sum rides in the CG r-update), "overlap_min_doubles" / "comm_rehearsal" (multi-GPU, below),
+ * "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
  * hmg_vec_create of the same size -- re-allocating freed device memory costs ~35 ms per GB here; 0 = free at once and
  * release what is held; hmg_ctx_destroy releases it too), "coarse_maxit", "coarse_check",
  * "time_apply"; "coarse_rtol" via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
