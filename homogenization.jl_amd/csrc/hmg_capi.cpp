@@ -297,6 +297,7 @@ struct hmg_grid {
     std::vector<double> part_coords;
     std::vector<int64_t> part_cells;
     std::vector<int32_t> part_owner, part_cut_owner;     // (part_cut_owner: rehearsal partitions only, else empty)
+    bool part_halo = true;                               // partition analysis on this rank's cells + one-cell halo (see create_partition)
     int64_t part_nnodes = 0, part_ncells = 0;
     DevBuf<int32_t> d_nodes_g, d_owned, d_cells_gnode;
     CutKind cut[3];   // faces, edges, nodes
@@ -1522,6 +1523,9 @@ CutLevel &cut_level(hmg_grid *g, const LevelDev &lv)
     hipStream_t st = g->ctx ? g->ctx->stream : nullptr;
     std::vector<int64_t> pos;
     if (!g->sharers) {
+        need(!g->part || g->part->global_ids,
+             "this partition was analysed on the rank's halo only: its cut ids mean nothing to other ranks -- exchange among "
+             "the sharers (hmg_grid_use_comm / hmg_grid_set_exchange_p2p) or create the grid with HMG_PARTITION_ANALYSIS=global");
         int64_t off = 0;
         for (int k = 0; k < 3; ++k) {
             pos.resize(g->cut[k].gid.size());
@@ -2084,7 +2088,14 @@ static int create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, 
     g->nlevels = nlevels;
     g->lt = build_level_tables(dim, nlevels);
     g->part.reset(new Partition);
-    build_partition(dim, nnodes, coords, ncells, cells, owner, rank, nranks, g->mesh_full, *g->part, cut_owner);
+    // The analysis looks at this rank's cells and their one-cell halo (the global pass keeps only what the replicated level-1
+    // system needs); HMG_PARTITION_ANALYSIS=global, or HMG_EXCHANGE=allreduce -- which needs cut ids every rank agrees on --,
+    // bring back the analysis of the whole mesh on every rank.
+    {
+        const char *pa = std::getenv("HMG_PARTITION_ANALYSIS"), *ex = std::getenv("HMG_EXCHANGE");
+        g->part_halo = !((pa && std::string(pa) == "global") || (ex && std::string(ex) == "allreduce"));
+    }
+    build_partition(dim, nnodes, coords, ncells, cells, owner, rank, nranks, g->mesh_full, *g->part, cut_owner, g->part_halo);
     g->part_coords.assign(coords, coords + (size_t)dim * nnodes);
     g->part_cells.assign(cells, cells + (size_t)(dim + 1) * ncells);
     g->part_owner.assign(owner, owner + ncells);
@@ -2160,7 +2171,7 @@ int hmg_grid_shrink(hmg_grid *g, int64_t ncells_prefix, int64_t nnodes_prefix)
         MeshTables local;
         build_partition(g->dim, nnodes_prefix, g->part_coords.data(), ncells_prefix, g->part_cells.data(),
                         g->part_owner.data(), rank, nranks, local, *np,
-                        g->part_cut_owner.empty() ? nullptr : g->part_cut_owner.data());
+                        g->part_cut_owner.empty() ? nullptr : g->part_cut_owner.data(), g->part_halo);
         need(local.ncells <= g->mesh_full.ncells, "shrunk partition is larger than the original one");
         g->mesh = std::move(local);
         g->part = std::move(np);

@@ -207,6 +207,11 @@ struct Partition {
     int64_t nglobal[3] = {0, 0, 0};
     std::vector<int64_t> gid[3];
     std::vector<int32_t> cell_lid[3];
+    // false: the analysis looked at this rank's cells and their one-cell halo only (the default).  The ids in gid[] then
+    // number this rank's cut entities and mean nothing to other ranks: the all-reduce over a global cut buffer is not
+    // available, the exchange runs among the sharers (segments below).  `global` then carries only what the replicated
+    // level-1 system needs (cells, geometry, node -> cells, first copies, boundary nodes).
+    bool global_ids = true;
     // The same cut entities grouped by WHO shares them (exchange among the sharers only): a segment is the set
     // of cut entities with one set of member ranks -- at octants: a quarter of a cut plane (2 ranks), half an axis line
     // (4 ranks), the centre node (8 ranks).  Only the segments this rank is a member of are listed, in an order every
@@ -228,9 +233,13 @@ struct Partition {
 // copies' cells differ in cut_owner[] instead of owner[] -- with owner = 0 everywhere and cut_owner = the octant of a
 // cell, one rank walks the cut-first cell lists, the pack / unpack kernels and the exchange of an 8-rank partition while
 // holding every copy itself (the sum over ranks is then the identity and the results equal the unpartitioned ones).
+// halo_only: analyse this rank's cells plus every cell that shares a node with one of them instead of the whole mesh --
+// all copies of every entity of a local cell live there, which is all that masks, multiplicities, first copies and the
+// sharer sets need; the global pass shrinks to what the replicated level-1 matrix needs (no entity lists are sorted for
+// it).  Same tables for the local cells, same segments in the same order; no global cut ids (Partition::global_ids).
 void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells_1based,
                      const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part,
-                     const int32_t *cut_owner = nullptr);
+                     const int32_t *cut_owner = nullptr, bool halo_only = false);
 
 std::string &last_error();
 

@@ -314,17 +314,143 @@ void restrict_mesh_tables(const MeshTables &full, int64_t ncells_prefix, int64_t
     build_from_cells0(M);
 }
 
+namespace {
+
+// What the replicated level-1 system needs of the GLOBAL mesh, without sorting a single entity list: cells, geometry, the
+// node -> cells map (cells are visited in ascending order: a counting sort), first copies, and the boundary nodes -- a face
+// (3D) / edge (2D) lies on the boundary iff no other cell around its first node contains all its nodes.
+void build_global_lean(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells_1based, MeshTables &M)
+{
+    if (dim != 2 && dim != 3) throw std::runtime_error("dim must be 2 or 3");
+    if (ncells <= 0 || nnodes <= 0) throw std::runtime_error("empty base mesh");
+    const int N = dim + 1;
+    M = MeshTables();
+    M.dim = dim;
+    M.nnodes = nnodes;
+    M.ncells = ncells;
+    M.coords.assign(coords, coords + (size_t)nnodes * dim);
+    M.cells.resize((size_t)ncells * N);
+    for (int64_t q = 0; q < ncells * N; ++q) {
+        const int64_t v = cells_1based[q] - 1;
+        if (v < 0 || v >= nnodes) throw std::runtime_error("base mesh: node index out of range (cells are 1-based)");
+        M.cells[q] = (int32_t)v;
+    }
+    for (int64_t c = 0; c < ncells; ++c)
+        for (int l = 0; l + 1 < N; ++l)
+            if (!(M.cells[c * N + l] < M.cells[c * N + l + 1]))
+                throw std::runtime_error("base mesh: every cell's node tuple must be strictly ascending");
+    M.node_all_ptr.assign(nnodes + 1, 0);
+    for (int64_t q = 0; q < ncells * N; ++q) M.node_all_ptr[M.cells[q] + 1] += 1;
+    for (int64_t g = 0; g < nnodes; ++g) M.node_all_ptr[g + 1] += M.node_all_ptr[g];
+    M.node_all_ent.resize((size_t)ncells * N);
+    {
+        std::vector<int32_t> fill(M.node_all_ptr.begin(), M.node_all_ptr.end() - 1);
+        for (int64_t c = 0; c < ncells; ++c)
+            for (int l = 0; l < N; ++l) M.node_all_ent[fill[M.cells[c * N + l]]++] = (int32_t)(c * 8 + l);
+    }
+    M.node_first.assign(nnodes, -1);
+    for (int64_t g = 0; g < nnodes; ++g)
+        if (M.node_all_ptr[g + 1] > M.node_all_ptr[g]) M.node_first[g] = M.node_all_ent[M.node_all_ptr[g]];
+    // boundary nodes
+    std::vector<uint8_t> flag(nnodes, 0);
+    const int nsub = dim == 3 ? 4 : 3, sublen = dim;        // faces of a tetrahedron / edges of a triangle
+    auto sub = [&](int f, int q) { return dim == 3 ? TET_FACES[f][q] : TRI_EDGES[f][q]; };
+    parallel_for(ncells, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) {
+            const int32_t *el = &M.cells[c * N];
+            for (int f = 0; f < nsub; ++f) {
+                int32_t nd[3];
+                for (int q = 0; q < sublen; ++q) nd[q] = el[sub(f, q)];
+                bool shared = false;
+                for (int32_t e = M.node_all_ptr[nd[0]]; e < M.node_all_ptr[nd[0] + 1] && !shared; ++e) {
+                    const int64_t o = M.node_all_ent[e] >> 3;
+                    if (o == c) continue;
+                    const int32_t *oe = &M.cells[o * N];
+                    int hit = 0;
+                    for (int q = 0; q < sublen; ++q)
+                        for (int l = 0; l < N; ++l) hit += oe[l] == nd[q];
+                    shared = hit == sublen;
+                }
+                if (!shared)
+                    for (int q = 0; q < sublen; ++q) flag[nd[q]] = 1;     // (benign race: every writer stores 1)
+            }
+        }
+    });
+    M.node_on_boundary.assign(flag.begin(), flag.end());
+    M.detj.resize(ncells);
+    M.jinv.resize((size_t)ncells * dim * dim);
+    std::vector<char> bad(1, 0);
+    parallel_for(ncells, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) {
+            Geo g = cell_geo(M, c);
+            if (!(g.det > 0.0)) bad[0] = 1;
+            M.detj[c] = g.det;
+            for (int b = 0; b < dim; ++b)
+                for (int a = 0; a < dim; ++a) M.jinv[(size_t)c * dim * dim + a + dim * b] = g.Jinv[a][b];
+        }
+    });
+    if (bad[0]) throw std::runtime_error("base mesh: degenerate cell");
+}
+
+}  // namespace
+
 void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncells, const int64_t *cells_1based,
                      const int32_t *owner, int rank, int nranks, MeshTables &local, Partition &part,
-                     const int32_t *cut_owner)
+                     const int32_t *cut_owner, bool halo_only)
 {
     const int32_t *cown = cut_owner ? cut_owner : owner;
     part.rank = rank;
     part.nranks = nranks;
+    part.global_ids = !halo_only;
     MeshTables &G = part.global;
-    EntLists glists;                         // the global entity lists, sorted once, reused for the cut analysis below
-    build_mesh_tables_keep(dim, nnodes, coords, ncells, cells_1based, G, &glists);
+    EntLists glists;                         // the entity lists, sorted once, reused for the cut analysis below
     const int N = dim + 1;
+    // halo mode: H = the local cells and every cell that shares a node with one (hcells: their global ids, ascending),
+    // analysed with node ids compressed monotonically -- the order of entity keys, hence of segments, is the global one
+    MeshTables H;
+    std::vector<int32_t> hcells, hcell_of;   // H cell -> global cell; global cell -> H cell or -1
+    if (halo_only) {
+        build_global_lean(dim, nnodes, coords, ncells, cells_1based, G);
+        std::vector<uint8_t> mark(nnodes, 0);
+        for (int64_t c = 0; c < ncells; ++c)
+            if (owner[c] == rank)
+                for (int l = 0; l < N; ++l) mark[G.cells[c * N + l]] = 1;
+        hcell_of.assign(ncells, -1);
+        for (int64_t c = 0; c < ncells; ++c) {
+            bool in = false;
+            for (int l = 0; l < N; ++l) in = in || mark[G.cells[c * N + l]];
+            if (in) {
+                hcell_of[c] = (int32_t)hcells.size();
+                hcells.push_back((int32_t)c);
+            }
+        }
+        std::vector<int32_t> hnode(nnodes, -1);
+        int32_t nh = 0;
+        {
+            std::vector<uint8_t> used(nnodes, 0);
+            for (int32_t c : hcells)
+                for (int l = 0; l < N; ++l) used[G.cells[(size_t)c * N + l]] = 1;
+            for (int64_t g = 0; g < nnodes; ++g)
+                if (used[g]) hnode[g] = nh++;
+        }
+        H.dim = dim;
+        H.nnodes = nh;
+        H.ncells = (int64_t)hcells.size();
+        H.coords.resize((size_t)nh * dim);
+        for (int64_t g = 0; g < nnodes; ++g)
+            if (hnode[g] >= 0)
+                for (int a = 0; a < dim; ++a) H.coords[(size_t)hnode[g] * dim + a] = coords[(size_t)g * dim + a];
+        H.cells.resize(hcells.size() * N);
+        for (size_t q = 0; q < hcells.size(); ++q)
+            for (int l = 0; l < N; ++l) H.cells[q * N + l] = hnode[G.cells[(size_t)hcells[q] * N + l]];
+        if (H.ncells >= (int64_t(1) << 27)) throw std::runtime_error("too many cells for one device partition");
+        build_from_cells0(H, &glists);
+    } else {
+        build_mesh_tables_keep(dim, nnodes, coords, ncells, cells_1based, G, &glists);
+    }
+    // tables the analysis reads (A) and the map from their cell numbering to global cell ids
+    const MeshTables &A = halo_only ? H : G;
+    auto gcell = [&](int32_t acell) -> int32_t { return halo_only ? hcells[(size_t)acell] : acell; };
     const int nface = dim == 3 ? 4 : 0, nedge = dim == 3 ? 6 : 3;
 
     // local cells / nodes in ascending global order (keeps every cell tuple ascending)
@@ -353,12 +479,12 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
         for (int l = 0; l < N; ++l) lcells[q * N + l] = (int64_t)node_l[G.cells[(size_t)part.cells_g[q] * N + l]] + 1;
     build_mesh_tables(dim, (int64_t)part.nodes_g.size(), lc.data(), (int64_t)part.cells_g.size(), lcells.data(), local);
 
-    // masks and multiplicities are properties of the GLOBAL mesh
+    // masks and multiplicities are properties of the GLOBAL mesh (in halo mode: every copy of a local cell's entity is in H)
     for (size_t q = 0; q < part.cells_g.size(); ++q) {
-        const int64_t c = part.cells_g[q];
-        local.dmask[q] = G.dmask[c];
-        local.dupmask[q] = G.dupmask[c];
-        for (int b = 0; b < 16; ++b) local.mult[q * 16 + b] = G.mult[(size_t)c * 16 + b];
+        const int64_t c = halo_only ? hcell_of[part.cells_g[q]] : part.cells_g[q];
+        local.dmask[q] = A.dmask[c];
+        local.dupmask[q] = A.dupmask[c];
+        for (int b = 0; b < 16; ++b) local.mult[q * 16 + b] = A.mult[(size_t)c * 16 + b];
     }
     part.owned_node.assign(part.nodes_g.size(), 0);
     for (size_t q = 0; q < part.nodes_g.size(); ++q) {
@@ -400,13 +526,17 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
         (void)nface;
         (void)nedge;
         for_groups(ents, [&](size_t i, size_t j) {
-            bool cut = false;
+            bool cut = false, mine = !halo_only;
             for (size_t q = i + 1; q < j; ++q)
-                if (cown[ents[q].cell] != cown[ents[i].cell]) cut = true;
+                if (cown[gcell(ents[q].cell)] != cown[gcell(ents[i].cell)]) cut = true;
             if (!cut) return;
+            if (halo_only) {                     // (groups without a local copy may be incomplete in H: not ours to judge)
+                for (size_t q = i; q < j; ++q) mine = mine || owner[gcell(ents[q].cell)] == rank;
+                if (!mine) return;
+            }
             const int64_t id = part.nglobal[kind]++;
             members.clear();
-            for (size_t q = i; q < j; ++q) members.push_back(owner[ents[q].cell]);
+            for (size_t q = i; q < j; ++q) members.push_back(owner[gcell(ents[q].cell)]);
             std::sort(members.begin(), members.end());
             members.erase(std::unique(members.begin(), members.end()), members.end());
             if (!std::binary_search(members.begin(), members.end(), (int32_t)rank)) return;
@@ -419,9 +549,9 @@ void build_partition(int dim, int64_t nnodes, const double *coords, int64_t ncel
             const int32_t sg = it->second;
             const int64_t idx = part.segs[sg].count[kind]++;
             for (size_t q = i; q < j; ++q)
-                if (owner[ents[q].cell] == rank) {
+                if (owner[gcell(ents[q].cell)] == rank) {
                     part.gid[kind].push_back(id);
-                    part.cell_lid[kind].push_back(cell_l[ents[q].cell] * 8 + ents[q].lid);
+                    part.cell_lid[kind].push_back(cell_l[gcell(ents[q].cell)] * 8 + ents[q].lid);
                     part.seg_of[kind].push_back(sg);
                     part.seg_idx[kind].push_back(idx);
                 }

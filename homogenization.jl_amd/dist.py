@@ -12,6 +12,7 @@ scalars and the gather of level-1 nodal values for the replicated coarse solve (
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -53,6 +54,7 @@ class PartitionedGrid(api.ImplicitFineGrid):
                 cells.ctypes.data_as(L.p_i64), own.ctypes.data_as(L.p_i32), cown.ctypes.data_as(L.p_i32), rank, nranks,
                 ctypes.byref(h)))
         self.h = h
+        self._fin = weakref.finalize(self, self._lib.hmg_grid_destroy, h)   # (as api.ImplicitFineGrid: vectors keep the grid alive)
         self.local_cells = self.table_i32("part_cells").astype(np.int64)     # global ids, ascending
         self.local_nodes = self.table_i32("part_nodes").astype(np.int64)
         inv = -np.ones(nodes.shape[0], dtype=np.int64)
@@ -66,7 +68,10 @@ class PartitionedGrid(api.ImplicitFineGrid):
         L.check(self._lib.hmg_grid_set_operator(self.h, s.ctypes.data_as(L.p_f64), float(lam)))
 
     def exchange_doubles(self):
-        return int(self._lib.hmg_grid_cut_buffer_doubles(self.h, 0))
+        n = int(self._lib.hmg_grid_cut_buffer_doubles(self.h, 0))
+        if n < 0:
+            raise L.HmgError(self._lib.hmg_last_error().decode())
+        return n
 
     def _refresh_local(self):
         nodes = self.global_base.nodes
@@ -132,6 +137,8 @@ class Exchange:
             L.check(lib.hmg_grid_use_comm(grid.h))
             grid._exchange = self
             return
+        if sharers:      # (the segment layout decides the buffer sizes: switch it on before asking for them)
+            L.check(lib.hmg_grid_set_exchange_p2p(grid.h, 1, L.P2P_FN(0), L.P2P_FN(0), None, 0))
         n = max(grid.exchange_doubles(), 1)
         self.buf = torch.zeros(n, dtype=torch.float64, device=dev)
         self.scal = torch.zeros(16, dtype=torch.float64, device=dev)
@@ -238,7 +245,6 @@ class Exchange:
         if sharers:
             # (the blocking transport serves as `begin` as well: by the time it returns the messages have landed, and the
             #  `end` callback above finds no work to wait for)
-            L.check(lib.hmg_grid_set_exchange_p2p(grid.h, 1, self._cb[4], self._cb[4], None, 0))
             ns = max(int(lib.hmg_grid_cut_stage_doubles(grid.h)), 1)
             self.stage = torch.zeros(ns, dtype=torch.float64, device=dev)
             ctx._keepalive.append(self.stage)

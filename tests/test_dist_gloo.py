@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, dim, shape, levels, q):
+def _worker(rank, world, port, dim, shape, levels, q, analysis="global"):
     try:
         sys.path.insert(0, ROOT)
         import torch
@@ -48,6 +48,7 @@ def _worker(rank, world, port, dim, shape, levels, q):
             blocks = hdist.block_shape(world, dim)
             width = shape[0] // blocks[0]
             owner = hdist.block_owner(base, blocks, width, origin)
+        os.environ["HMG_PARTITION_ANALYSIS"] = analysis          # "global": cut ids every rank agrees on (all-reduce form too)
         g = hdist.PartitionedGrid(None, base, levels, owner, rank, world)
         gm = O.Mesh(base.nodes, base.elements - 1)
         lm = O.Mesh(g.base.nodes, g.base.elements - 1)
@@ -100,31 +101,33 @@ def _worker(rank, world, port, dim, shape, levels, q):
         O.broadcast_interfaces(yl, li, L)
         counts = g.table_i32("cut_counts")
         per = {"faces": nfi, "edges": nei, "nodes": 1}
+        global_ids = analysis == "global"
         offs = {"faces": off_face, "edges": off_edge, "nodes": 0}
-        tot = counts[0] * nfi + counts[1] * nei + counts[2]
-        assert tot <= g.exchange_doubles()
-        buf = torch.zeros(max(tot, 1), dtype=torch.float64)
-        base_off = {"faces": 0, "edges": counts[0] * nfi, "nodes": counts[0] * nfi + counts[1] * nei}
-        views = {}
-        for kind in ("faces", "edges", "nodes"):
-            gid = g.table_i32("cut_gid_" + kind).astype(np.int64)
-            ce = g.table_i32("cut_ent_" + kind).astype(np.int64)
-            if per[kind] == 0 or gid.size == 0:
-                continue
-            k = np.arange(per[kind])
-            slots = offs[kind] + (ce & 7)[:, None] * per[kind] + k[None, :]
-            rows, cols = s2h[slots], (ce >> 3)[:, None] + 0 * k[None, :]
-            dst = base_off[kind] + gid[:, None] * per[kind] + k[None, :]
-            first = np.zeros(gid.size, dtype=bool)
-            first[np.unique(gid, return_index=True)[1]] = True
-            buf[torch.from_numpy(dst[first].ravel())] = torch.from_numpy(yl[rows[first], cols[first]].ravel())
-            views[kind] = (rows, cols, dst)
         yl_local = yl.copy(order="F")                                     # (kept for the second form of the exchange below)
-        dist.all_reduce(buf)
-        for kind, (rows, cols, dst) in views.items():
-            yl[rows, cols] = buf[torch.from_numpy(dst.ravel())].numpy().reshape(dst.shape)
-        err = np.abs(yl - ysum[:, g.local_cells]).max() / np.abs(ysum).max()
-        assert err <= 1e-13, err
+        tot = counts[0] * nfi + counts[1] * nei + counts[2]
+        if global_ids:                                                    # (a halo-only analysis has no ids the ranks agree on)
+            assert tot <= g.exchange_doubles()
+            buf = torch.zeros(max(tot, 1), dtype=torch.float64)
+            base_off = {"faces": 0, "edges": counts[0] * nfi, "nodes": counts[0] * nfi + counts[1] * nei}
+            views = {}
+            for kind in ("faces", "edges", "nodes"):
+                gid = g.table_i32("cut_gid_" + kind).astype(np.int64)
+                ce = g.table_i32("cut_ent_" + kind).astype(np.int64)
+                if per[kind] == 0 or gid.size == 0:
+                    continue
+                k = np.arange(per[kind])
+                slots = offs[kind] + (ce & 7)[:, None] * per[kind] + k[None, :]
+                rows, cols = s2h[slots], (ce >> 3)[:, None] + 0 * k[None, :]
+                dst = base_off[kind] + gid[:, None] * per[kind] + k[None, :]
+                first = np.zeros(gid.size, dtype=bool)
+                first[np.unique(gid, return_index=True)[1]] = True
+                buf[torch.from_numpy(dst[first].ravel())] = torch.from_numpy(yl[rows[first], cols[first]].ravel())
+                views[kind] = (rows, cols, dst)
+            dist.all_reduce(buf)
+            for kind, (rows, cols, dst) in views.items():
+                yl[rows, cols] = buf[torch.from_numpy(dst.ravel())].numpy().reshape(dst.shape)
+            err = np.abs(yl - ysum[:, g.local_cells]).max() / np.abs(ysum).max()
+            assert err <= 1e-13, err
         # ---- the same exchange among the SHARERS only (hmg_grid_set_exchange_p2p): segments = cut entities grouped by the
         # set of ranks that share them; per segment and peer one message each way, then the members' partials are added in
         # ascending rank order.  Layout, message list and order come from the library's tables, the transport is gloo.
@@ -198,7 +201,7 @@ def _worker(rank, world, port, dim, shape, levels, q):
         assert err <= 1e-13, err
         # what it saves: doubles this rank sends vs the all-reduce buffer every rank pushes through the ring
         sent = torch.tensor([float(msgs[:, 2].sum()) if len(msgs) else 0.0, float(tot)], dtype=torch.float64)
-        if world == 8:
+        if world == 8 and global_ids:
             assert sent[0].item() * 2 <= sent[1].item(), sent          # octants: at least a factor 2
         HL.check(HL.load().hmg_grid_set_exchange_p2p(g.h, 0, HL.P2P_FN(0), HL.P2P_FN(0), None, 0))
         # first-copy masks give each DOF exactly once across ranks
@@ -234,12 +237,15 @@ def _worker(rank, world, port, dim, shape, levels, q):
 @pytest.mark.parametrize("world,dim,shape,levels", [(2, 3, (4, 2, 2), 4), (4, 3, (4, 4, 2), 3), (2, 2, (6, 3), 4),
                                                       (3, 3, "delaunay", 3), (2, 2, "delaunay", 4),
                                                       (8, 3, (4, 4, 4), 3)])   # octants: centre node shared by 8 ranks
-def test_partitioned_interface_sum_matches_serial(world, dim, shape, levels):
+@pytest.mark.parametrize("analysis", ["global", "halo"])
+def test_partitioned_interface_sum_matches_serial(world, dim, shape, levels, analysis):
+    """analysis = "halo" (the default of hmg_grid_create_partition): every rank analyses its own cells and their one-cell halo
+    only; "global": the whole mesh on every rank (needed by the all-reduce form of the exchange, which is checked there too)."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dim, shape, levels, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dim, shape, levels, q, analysis)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
@@ -249,13 +255,14 @@ def test_partitioned_interface_sum_matches_serial(world, dim, shape, levels):
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
-def test_synthetic_cut_tables_match_the_eight_rank_partition():
+def test_synthetic_cut_tables_match_the_eight_rank_partition(monkeypatch):
     """Rehearsal partition (hmg_grid_create_partition_rehearsal): one rank holds every cell, cut_owner = the octant of a
     cell.  The cut entities are those of the real 8-rank partition (same global counts, same ids); every copy is local;
     the cut face pairs lead the pair list; edge / node groups and cells are split cut-first as in a real partition."""
     sys.path.insert(0, ROOT)
     import homogenization_jl_amd as hmg
     from homogenization_jl_amd import dist as hdist, driver
+    monkeypatch.setenv("HMG_PARTITION_ANALYSIS", "global")           # (the comparison is by global cut id)
     w, L = 4, 3
     base = driver.checkerboard_mesh(hmg.Tet64, (w, w, w), origin=(-w / 2.0,) * 3, transposed_lookup=False)
     octant = hdist.block_owner(base, (2, 2, 2), w // 2, (-w / 2.0,) * 3)
@@ -291,3 +298,69 @@ def test_synthetic_cut_tables_match_the_eight_rank_partition():
     # without cut_owner a one-rank partition has no cut at all
     plain = hdist.PartitionedGrid(None, base, L, zero, 0, 1)
     assert not plain.table_i32("cut_counts").any() or plain.table_i32("cut_counts")[10] == base.elements.shape[0]
+
+
+@pytest.mark.parametrize("world,dim,shape", [(2, 3, (4, 2, 2)), (8, 3, (4, 4, 4)), (4, 2, (6, 6)), (3, 3, "delaunay"), (2, 2, "delaunay")])
+def test_halo_analysis_equals_global_analysis(world, dim, shape):
+    """Partition analysis on a rank's cells plus their one-cell halo (hmg_grid_create_partition's default) against the analysis of
+    the whole mesh: local mesh, Dirichlet / first-copy masks, multiplicities, node ownership, the cut copies, the segments (members,
+    counts, order), every copy's place inside its segment, the message list and the replicated level-1 matrix are identical; only the
+    global cut ids -- which the halo analysis cannot know and the exchange among the sharers does not need -- are gone."""
+    sys.path.insert(0, ROOT)
+    import ctypes
+    import homogenization_jl_amd as hmg
+    from homogenization_jl_amd import driver, dist as hdist, _lib as HL
+    levels = 3
+    tag = hmg.Tet64 if dim == 3 else hmg.Tri64
+    if shape == "delaunay":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _meshes import delaunay_mesh
+        from oracle import oracle as O
+        dm = delaunay_mesh(O, dim, 70, 13)
+        base = hmg.Mesh(dm.nodes, dm.elements + 1)
+        owner = ((np.arange(dm.nelements()) * 2654435761 >> 7) % world).astype(np.int32)
+    else:
+        origin = tuple(-s / 2.0 for s in shape)
+        base = driver.order_nodes_and_elements_by_magnitude(driver.box_mesh(tag, shape, origin=origin))
+        blocks = hdist.block_shape(world, dim)
+        owner = hdist.block_owner(base, blocks, shape[0] // blocks[0], origin)
+    rng = np.random.default_rng(5)
+    sig = rng.choice([1.0, 9.0], size=(base.elements.shape[0], dim))
+    lib = HL.load()
+    old = os.environ.get("HMG_PARTITION_ANALYSIS")
+    try:
+        for rank in range(world):
+            grids = {}
+            for mode in ("global", "halo"):
+                os.environ["HMG_PARTITION_ANALYSIS"] = mode
+                g = hdist.PartitionedGrid(None, base, levels, owner, rank, world)
+                HL.check(lib.hmg_grid_set_exchange_p2p(g.h, 1, HL.P2P_FN(0), HL.P2P_FN(0), None, 0))
+                g.set_operator(sig, 0.7)
+                g.coarse_setup()
+                grids[mode] = g
+            a, b = grids["global"], grids["halo"]
+            for name in ("part_cells", "part_nodes", "part_owned", "dmask", "dupmask", "mult", "face_pairs", "edge_ptr", "edge_ent",
+                         "node_ptr", "node_ent", "node_first", "seg_ptr", "seg_members", "seg_counts", "cut_ent_faces", "cut_ent_edges",
+                         "cut_ent_nodes", "cut_seg_faces", "cut_seg_edges", "cut_seg_nodes", "cut_sidx_faces", "cut_sidx_edges",
+                         "cut_sidx_nodes", "coarse_rowptr", "coarse_colidx"):
+                np.testing.assert_array_equal(a.table_i32(name), b.table_i32(name), err_msg=f"rank {rank}: {name}")
+            np.testing.assert_array_equal(a.table_i32("cut_counts")[3:], b.table_i32("cut_counts")[3:])
+            np.testing.assert_array_equal(a.table_f64("coarse_val"), b.table_f64("coarse_val"))
+            np.testing.assert_array_equal(a.table_f64("coef"), b.table_f64("coef"))
+            for lev in range(1, levels + 1):
+                msgs = []
+                for g in (a, b):
+                    n = ctypes.c_int64()
+                    HL.check(lib.hmg_grid_exchange_messages(g.h, lev, None, 0, ctypes.byref(n)))
+                    m = np.zeros(n.value, dtype=np.int64)
+                    HL.check(lib.hmg_grid_exchange_messages(g.h, lev, m.ctypes.data_as(HL.p_i64), m.size, ctypes.byref(n)))
+                    msgs.append(m)
+                np.testing.assert_array_equal(msgs[0], msgs[1])
+            # the all-reduce form is refused on the halo grid instead of summing apples and oranges
+            HL.check(lib.hmg_grid_set_exchange_p2p(b.h, 0, HL.P2P_FN(0), HL.P2P_FN(0), None, 0))
+            assert lib.hmg_grid_cut_buffer_doubles(b.h, levels) == -1 and b"halo" in lib.hmg_last_error()
+    finally:
+        if old is None:
+            os.environ.pop("HMG_PARTITION_ANALYSIS", None)
+        else:
+            os.environ["HMG_PARTITION_ANALYSIS"] = old
