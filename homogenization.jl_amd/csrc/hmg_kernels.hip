@@ -367,7 +367,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                         } else if (x2c)
                             v = v + beta * x2v[q];
                         if (xoc) xoc[t] = v;
-                        rr += v * v;
+                        if (!RS) rr += v * v;      // (RS: the local residual -- nobody asks for its reductions)
                     }
                     xs[lp[q]] = v;
                 }
@@ -422,7 +422,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         if (!wdot) o = sv + o;
         if ((dm >> (cls - 1)) & 1u) o = 0.0;
         if (!FUSED || oc) oc[t] = o;
-        if (FUSED) {
+        if (FUSED && !RS) {
             const int e = cls - 1;
             const uint32_t word = e < 4 ? mq[0] : e < 8 ? mq[1] : e < 12 ? mq[2] : mq[3];
             const uint32_t mu = (word >> (8 * (e & 3))) & 0xffu;
@@ -453,13 +453,13 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             if (face >= 4)
                 ;
             else if (face == 0)
-                face_items<0, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
+                face_items<0, FI, FUSED, FUSED && !RS>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
             else if (face == 1)
-                face_items<1, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
+                face_items<1, FI, FUSED, FUSED && !RS>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
             else if (face == 2)
-                face_items<2, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
+                face_items<2, FI, FUSED, FUSED && !RS>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
             else
-                face_items<3, FI, FUSED>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
+                face_items<3, FI, FUSED, FUSED && !RS>(wv, 16, xs, m, lv.nfi, fbase, ft0, fw, fdir, fmult, sc, oc, pap, lane, nopre, false, wdot, RS ? kf : nullptr);
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 if (edge[q] < 0) continue;
@@ -469,12 +469,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 const double nop1[1] = {0.0};
                 const int wl = 32 + 16 * q;
                 switch (edge[q]) {
-                case 0: class_items<edge_tap_mask(0), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
-                case 1: class_items<edge_tap_mask(1), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
-                case 2: class_items<edge_tap_mask(2), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
-                case 3: class_items<edge_tap_mask(3), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
-                case 4: class_items<edge_tap_mask(4), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
-                default: class_items<edge_tap_mask(5), 1, FUSED>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 0: class_items<edge_tap_mask(0), 1, FUSED, FUSED && !RS>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 1: class_items<edge_tap_mask(1), 1, FUSED, FUSED && !RS>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 2: class_items<edge_tap_mask(2), 1, FUSED, FUSED && !RS>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 3: class_items<edge_tap_mask(3), 1, FUSED, FUSED && !RS>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                case 4: class_items<edge_tap_mask(4), 1, FUSED, FUSED && !RS>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
+                default: class_items<edge_tap_mask(5), 1, FUSED, FUSED && !RS>(wv, wl, xs, m, lv.nei, ebase[q], 0, ew[q], edir, emult, sc, oc, pap, lane, nop1, false, wdot, RS ? &ke[q] : nullptr); break;
                 }
             }
             if (wave == NW - 1 && lane < lv.ncorner) kc = surface_node(lane, cw);
@@ -541,28 +541,45 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // EVEN lattice nodes, taps that leave the cell weighted 0 -- tap for tap the arithmetic of the stand-alone restriction
         // (k_apply_slab with flags bit 2), so the coarse vector is the same to the last bit.  The residual itself need not go
         // to HBM at all (oc == nullptr): 16 B per fine DOF and one launch less per V-cycle.
+        // (the image positions are fetched again here, in front of the barrier that hides their latency, instead of keeping the
+        //  addressing words of the evaluation alive across the kernel: held, one of them was spilled, and every reload of a spilled
+        //  register waits for ALL outstanding global loads -- vmcnt(0) -- in the middle of the face runs)
+        int fl[FI], el[NE], cl = 0;
+        uint32_t b0 = 0u, b1 = 0u;
+        if (face < 4) {
+#pragma unroll
+            for (int q = 0; q < FI; ++q) {
+                const int ti = ft0 + q * 64 + lane;
+                fl[q] = ti < lv.nfi ? (int)lv.lpos[lv.off_face + face * lv.nfi + ti] : 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NE; ++q) el[q] = edge[q] >= 0 && lane < lv.nei ? (int)lv.lpos[ebase[q] + lane] : 0;
+        if (wave == NW - 1 && lane < lv.ncorner) cl = (int)lv.lpos[lane];
+        if (tid < nsw) b0 = lv.blk_word[tid];
+        if (NPASS > 1 && tid + NT < nsw) b1 = lv.blk_word[tid + NT];
         __syncthreads();
         if (face < 4) {
 #pragma unroll
             for (int q = 0; q < FI; ++q)
-                if (ft0 + q * 64 + lane < lv.nfi) xs[fw[q] & 0xffffu] = kf[q];
+                if (ft0 + q * 64 + lane < lv.nfi) xs[fl[q]] = kf[q];
         }
 #pragma unroll
         for (int q = 0; q < NE; ++q)
-            if (edge[q] >= 0 && lane < lv.nei) xs[ew[q][0] & 0xffffu] = ke[q];
-        if (wave == NW - 1 && lane < lv.ncorner) xs[cw & 0xffffu] = kc;
+            if (edge[q] >= 0 && lane < lv.nei) xs[el[q]] = ke[q];
+        if (wave == NW - 1 && lane < lv.ncorner) xs[cl] = kc;
         {
             int pos[RB ? RB : 1];
             if (tid < nsw) {
-                block_positions<RB ? RB : 1>(m, q0, pos);
-                const int nv = (int)(q0 >> 28);
+                block_positions<RB ? RB : 1>(m, b0, pos);
+                const int nv = (int)(b0 >> 28);
 #pragma unroll
                 for (int r = 0; r < (RB ? RB : 1); ++r)
                     if (r < nv) xs[pos[r]] = ki[0][r];
             }
             if (NPASS > 1 && tid + NT < nsw) {
-                block_positions<RB ? RB : 1>(m, q1, pos);
-                const int nv = (int)(q1 >> 28);
+                block_positions<RB ? RB : 1>(m, b1, pos);
+                const int nv = (int)(b1 >> 28);
 #pragma unroll
                 for (int r = 0; r < (RB ? RB : 1); ++r)
                     if (r < nv) xs[pos[r]] = ki[NPASS - 1][r];
@@ -608,7 +625,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             rc[c] = 0.0 + acc;               // (the stand-alone kernel adds its absent source value first: 0 + acc)
         }
     }
-    if (FUSED) {
+    if (FUSED && !RS) {
         __syncthreads();                     // W / xs no longer read: reuse the front of LDS for the reduction
         const double s_pap = block_sum(pap, smem);
         const double s_rr = block_sum(rr, smem);

@@ -203,7 +203,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // Face-interior nodes, one entity class per wave: the class weight row sits in SGPRs (one LDS read + readlanes per
 // wave instead of 15 LDS reads per node) and only the 11 taps that exist are read -- 11 LDS reads per node instead
 // of 30.  A wave evaluates up to NITEM runs of 64 consecutive slots of face F; fw[] holds their addressing words.
-template <uint32_t M, int NITEM, bool FUSED>
+template <uint32_t M, int NITEM, bool FUSED, bool PAP = FUSED>
 __device__ __forceinline__ void class_items(double wv, int wlane0, const double *xs, int m, int nfi, int slot_base, int t0,
                                             const uint32_t (&fw)[NITEM], bool dirichlet, double mult, const double *sc,
                                             double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre,
@@ -244,7 +244,7 @@ __device__ __forceinline__ void class_items(double wv, int wlane0, const double 
                 if ((M >> 13) & 1u) acc += w[13] * lds_ld(pu + 1 - len);
                 if ((M >> 14) & 1u) acc += w[14] * lds_ld(pd + len);
                 o = wdot ? acc : sv + acc;
-                if (FUSED) pap += mult * ((wdot ? ctr + sv : ctr) * o);
+                if (PAP) pap += mult * ((wdot ? ctr + sv : ctr) * o);
             }
             if (!FUSED || oc) oc[t] = o;
             if (keep) keep[q] = o;
@@ -252,14 +252,14 @@ __device__ __forceinline__ void class_items(double wv, int wlane0, const double 
     }
 }
 
-template <int F, int NITEM, bool FUSED>
+template <int F, int NITEM, bool FUSED, bool PAP = FUSED>
 __device__ __forceinline__ void face_items(double wv, int wlane0, const double *xs, int m, int nfi, int slot_base, int t0,
                                            const uint32_t (&fw)[NITEM], bool dirichlet, double mult, const double *sc,
                                            double *oc, double &pap, int lane, const double (&pre)[NITEM], bool use_pre,
                                            bool wdot = false, double *keep = nullptr)
 {
-    class_items<face_tap_mask(F), NITEM, FUSED>(wv, wlane0, xs, m, nfi, slot_base, t0, fw, dirichlet, mult, sc, oc, pap, lane,
-                                                pre, use_pre, wdot, keep);
+    class_items<face_tap_mask(F), NITEM, FUSED, PAP>(wv, wlane0, xs, m, nfi, slot_base, t0, fw, dirichlet, mult, sc, oc, pap, lane,
+                                                     pre, use_pre, wdot, keep);
 }
 
 // Edge e of the reference simplex lies on two faces (edge order of the reference: (1,2) (1,3) (1,4) (2,3) (2,4) (3,4) =
