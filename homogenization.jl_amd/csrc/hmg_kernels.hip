@@ -407,15 +407,6 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     const int nsurf = lv.off_int;
     const int nsw = RB ? lv.nblk : lv.nsweep;
     const bool wdot = WD && FUSED && (a.flags & 8);   // src multiplies: out = alpha A x, pap += mult (x + src) out
-    // Register-blocked instantiations with a source vector (residuals): the source values of this thread's interior blocks are
-    // requested HERE, in front of the barrier (their addresses come from the block words just fetched), so that the first FMA
-    // of a block walk does not wait a memory round trip for them.  (Not for the driver integrals, whose source multiplies.)
-    // Only the FIRST pass's values are held across the barrier (and, where the surface comes first, across the surface phase): the
-    // second pass's are requested when the first pass starts.  Compiled into the plain kernel only (the residual r = b - A x): in the
-    // fused instantiations -- also the two that always carry a source vector, RS and CG -- the held registers spill (36-80 B).
-    constexpr bool PRESRC = RB != 0 && DIM == 3 && !WD && !FUSED;
-    double ps[NPASS][RB ? RB : 1];
-    if (PRESRC && sc && tid < nsw) block_sources<RB ? RB : 1>(m, q0, s0, sc, ps[0]);
     HMG_STAMP(2);   // tables requested, before the barrier
     __syncthreads();
     HMG_STAMP(3);
@@ -448,11 +439,8 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         double w0e[15];
 #pragma unroll
         for (int d = 0; d < NDIR; ++d) w0e[d] = readlane_f64(wv, d);
-        if (NPASS > 1 && PRESRC && sc && tid + NT < nsw) block_sources<RB ? RB : 1>(m, q1, s1, sc, ps[NPASS - 1]);
-        if (tid < nsw) interior_block_keep<RB ? RB : 1, FUSED>(w0e, xs, m, nf >> 1, q0, s0, sc, oc, ki[0], PRESRC && sc ? ps[0] : nullptr);
-        if (NPASS > 1 && tid + NT < nsw)
-            interior_block_keep<RB ? RB : 1, FUSED>(w0e, xs, m, nf >> 1, q1, s1, sc, oc, ki[NPASS - 1],
-                                                    PRESRC && sc ? ps[NPASS - 1] : nullptr);
+        if (tid < nsw) interior_block_keep<RB ? RB : 1, FUSED>(w0e, xs, m, nf >> 1, q0, s0, sc, oc, ki[0]);
+        if (NPASS > 1 && tid + NT < nsw) interior_block_keep<RB ? RB : 1, FUSED>(w0e, xs, m, nf >> 1, q1, s1, sc, oc, ki[NPASS - 1]);
     }
     if (RB) {
         if (DIM == 3) {
@@ -510,16 +498,15 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // register-blocked interior: one pass (the host selects this instantiation only if nblk <= NT), its word
         // was fetched before the barrier
         if constexpr (!RS) {
-        if (DIM == 3 && NPASS > 1 && PRESRC && sc && tid + NT < nsw) block_sources<RB ? RB : 1>(m, q1, s1, sc, ps[NPASS - 1]);
         if (DIM == 3 && tid < nsw) {
             if (sc)
-                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap, wdot, PRESRC ? ps[0] : nullptr);
+                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap, wdot);
             else
                 interior_block<RB ? RB : 1, FUSED, false>(w0, xs, m, nf >> 1, q0, s0, sc, oc, pap);
         }
         if (DIM == 3 && NPASS > 1 && tid + NT < nsw) {      // second pass (the host selects NT >= nblk / 2)
             if (sc)
-                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q1, s1, sc, oc, pap, wdot, PRESRC ? ps[NPASS - 1] : nullptr);
+                interior_block<RB ? RB : 1, FUSED, true>(w0, xs, m, nf >> 1, q1, s1, sc, oc, pap, wdot);
             else
                 interior_block<RB ? RB : 1, FUSED, false>(w0, xs, m, nf >> 1, q1, s1, sc, oc, pap);
         }

@@ -387,27 +387,11 @@ __device__ __forceinline__ void block_positions(int m, uint32_t word, int (&pos)
 }
 
 // ... with the results handed back in res[] (KEEP form: out = src + alpha A x, no p.Ap)
-// Source values of a block (out = src + alpha A x), requested early: the caller issues these loads in front of the workgroup
-// barrier so that their latency hides behind it instead of in front of the first FMA of the block walk.
-template <int R>
-__device__ __forceinline__ void block_sources(int m, uint32_t word, int slot0, const double *sc, double (&pre)[R])
-{
-    int slot[R];
-    block_slots<R>(m, word, slot0, slot);
-    const int nv = (int)(word >> 28);
-#pragma unroll
-    for (int r = 0; r < R; ++r) pre[r] = r < nv ? sc[slot[r]] : 0.0;
-}
-
 template <int R, bool FUSED>
 __device__ __forceinline__ void interior_block_keep(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
-                                                    int slot0, const double *sc, double *oc, double (&res)[R],
-                                                    const double *pre = nullptr)
+                                                    int slot0, const double *sc, double *oc, double (&res)[R])
 {
-    if (pre) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) res[r] = pre[r];
-    } else if (sc) {
+    if (sc) {
         int slot[R];
         block_slots<R>(m, word, slot0, slot);
         const int nv = (int)(word >> 28);
@@ -423,21 +407,15 @@ __device__ __forceinline__ void interior_block_keep(const double (&w)[15], const
 
 template <int R, bool FUSED, bool SRC>
 __device__ __forceinline__ void interior_block(const double (&w)[15], const double *xs, int m, int safe, uint32_t word,
-                                               int slot0, const double *sc, double *oc, double &pap, bool wdot = false,
-                                               const double *pre = nullptr)
+                                               int slot0, const double *sc, double *oc, double &pap, bool wdot = false)
 {
     double acc[R];
     if (SRC) {
-        if (pre) {
+        int slot[R];
+        block_slots<R>(m, word, slot0, slot);
+        const int nv = (int)(word >> 28);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = pre[r];
-        } else {
-            int slot[R];
-            block_slots<R>(m, word, slot0, slot);
-            const int nv = (int)(word >> 28);
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = r < nv ? sc[slot[r]] : 0.0;
-        }
+        for (int r = 0; r < R; ++r) acc[r] = r < nv ? sc[slot[r]] : 0.0;
         if (FUSED && wdot) {                 // the source values multiply (see class_items)
             double wsv[R];
 #pragma unroll
