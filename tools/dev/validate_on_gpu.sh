@@ -28,4 +28,16 @@ for l in sys.stdin:
     d = json.loads(l); print(round(d['ms_per_step'],2), '%.3e' % d['value'], round(d['roofline']['avg_launch_ms'],3), round(d['roofline']['frac'],3), d['config']['residual_norm_after'], d['config']['workload'][:90])
 " | tee $O/summary.txt
 bash $R/tools/collect_profiles.sh r03 > $O/collect.log 2>&1 && bash $R/tools/dev/apply_sequence.sh > $O/sequence.log 2>&1
-echo done
+echo main part done
+# kernel tables of the partition rehearsals on this build (profiles/r03_partitioned_kernel_stats_final.csv is made from them)
+cd /tmp; export TMPDIR=/tmp
+T="--no-cpu-baseline --no-time-to-tolerance --steps 2 --warmup 1"
+step 600 trace_new rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_new -- python3 $R/bench.py $T
+HMG_SYNTHETIC_CUT=planes step 600 trace_syn rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_syn -- python3 $R/bench.py $T
+HMG_REHEARSE_WORLD=8 step 600 trace_r8 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_r8 -- python3 $R/bench.py $T
+for t in trace_new trace_syn trace_r8; do
+  F=$(ls -t $O/$t/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$F" ] && cp $F $O/$t.kernel_stats.csv
+  rm -rf $O/$t
+done
+echo traces done
