@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU call that validates a build (used at the end of round 3): whole GPU suite, smoke(), the default bench line, a 2-rank rehearsal of bench.py's N > 1 path over gloo, profiles.
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/validate; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/validate_${1:-main}; rm -rf $O; mkdir -p $O
 cd $R
 step() {  # step <seconds> <name> <cmd...>
     local t=$1 n=$2; shift 2
@@ -11,6 +11,8 @@ step() {  # step <seconds> <name> <cmd...>
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $n: stopping" | tee -a $O/steps.log; exit 1; fi
     return 0
 }
+PART=${1:-main}
+if [ "$PART" = main ]; then
 step 1100 tests_all python3 -m pytest tests -q -m gpu
 tail -n 4 $O/tests_all.log
 step 300 smoke python3 __graft_entry__.py smoke
@@ -27,8 +29,10 @@ import sys, json
 for l in sys.stdin:
     d = json.loads(l); print(round(d['ms_per_step'],2), '%.3e' % d['value'], round(d['roofline']['avg_launch_ms'],3), round(d['roofline']['frac'],3), d['config']['residual_norm_after'], d['config']['workload'][:90])
 " | tee $O/summary.txt
-bash $R/tools/collect_profiles.sh r03 > $O/collect.log 2>&1 && bash $R/tools/dev/apply_sequence.sh > $O/sequence.log 2>&1
 echo main part done
+exit 0
+fi
+bash $R/tools/collect_profiles.sh r03 > $O/collect.log 2>&1 && bash $R/tools/dev/apply_sequence.sh > $O/sequence.log 2>&1
 # kernel tables of the partition rehearsals on this build (profiles/r03_partitioned_kernel_stats_final.csv is made from them)
 cd /tmp; export TMPDIR=/tmp
 T="--no-cpu-baseline --no-time-to-tolerance --steps 2 --warmup 1"
