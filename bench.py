@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--cpu-driver-seconds", type=float, default=75.0,
                     help="time limit of the CPU oracle's run of the driver on BASELINE config 2")
     ap.add_argument("--apply-threads", type=int, default=None)
+    ap.add_argument("--tune-placement", type=int, default=8,
+                    help="candidates of hmg_level_tune_placement for the finest level's five vectors (setup, untimed); 0 = off")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -227,6 +229,17 @@ def main():
 
     states = [hmg.LevelState(implicit, i + 1) for i in range(L)]
     top = states[-1]
+    placement = {"tuned": False}
+    if args.tune_placement > 0:
+        # setup, like an FFT plan: which of the finest level's memory blocks (+ 2 spare ones, freed again) plays x, b, r, p,
+        # Ap is chosen by timing that level's share of a V-cycle per candidate (include/hmg.h, hmg_level_tune_placement)
+        ctx.sync()
+        t_tune0 = time.perf_counter()
+        before, after = hmg.tune_placement(implicit, [op] * L, states, L, args.smoothing_steps, trials=args.tune_placement, extra=2)
+        ctx.sync()
+        placement = {"tuned": True, "candidates": args.tune_placement, "spare_blocks": 2,
+                     "finest_level_share_of_a_vcycle_ms_as_allocated": before, "finest_level_share_of_a_vcycle_ms_chosen": after,
+                     "seconds": time.perf_counter() - t_tune0}
     top.x.rand(1234, cell_offset=rank * ne_local)
     hmg.broadcast_interfaces(top.x, implicit, L)
     hmg.apply_constraint(top.x, L, implicit)
@@ -302,7 +315,7 @@ def main():
                        "smoothing_steps": args.smoothing_steps, "smoothing_steps_coarse": 2,
                        "coarse_solver": "device Jacobi-PCG rtol 1e-13",
                        "coarse_iterations_last": base_level.last_iterations(),
-                       "setup_seconds": setup_seconds,
+                       "setup_seconds": setup_seconds, "placement": placement,
                        "residual_norm_after": rnorm},
             "roofline": {"bound": "hbm",
                          "kernel": ("hmg::k_apply<3,512,13,*,6> (finest-level operator apply, three 512-thread workgroups per CU"

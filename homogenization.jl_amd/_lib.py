@@ -73,6 +73,7 @@ SIGNATURES = {
     "hmg_gather_base": (c_int, [vp, vp, p_f64]),
     "hmg_scatter_base": (c_int, [vp, p_f64, vp]),
     "hmg_smooth": (c_int, [vp, c_int, c_int, vp, vp, vp, vp, vp]),
+    "hmg_level_tune_placement": (c_int, [vp, c_int, c_int, pp, c_int, c_int, p_f64]),
     "hmg_coarse_setup": (c_int, [vp]),
     "hmg_coarse_solve": (c_int, [vp, vp, vp]),
     "hmg_coarse_last_iterations": (c_int, [vp]),

@@ -506,6 +506,16 @@ def _state_handles(levels):
     return arr
 
 
+def tune_placement(implicit: ImplicitFineGrid, ops, levels, k: int, steps: int = 3, trials: int = 8, extra: int = 2):
+    """hmg_level_tune_placement: which memory block plays x, b, r, p, Ap of levels[k-1] is chosen by timing level k's share
+    of a V-cycle (down + up half, levels[k-2] as the coarse side) per candidate assignment.  Call it on fresh states: the
+    vectors of both levels come back zero-filled.  Returns (ms before, ms after)."""
+    ops[k - 1]._bind()
+    ms = (ctypes.c_double * 2)()
+    L.check(L.load().hmg_level_tune_placement(implicit.h, k, int(steps), _state_handles(levels), int(extra), int(trials), ms))
+    return ms[0], ms[1]
+
+
 def vcycle_down(implicit: ImplicitFineGrid, ops, levels, k: int, steps: int = 2):
     """First half of one level of vcycle! (src/multigrid.jl:100-106): smoothing_steps!, local_residual!,
     restrict_to!(next.b, P, curr.r), fill!(next.x, 0).  Only levels[k-1] and levels[k-2] are touched (other entries

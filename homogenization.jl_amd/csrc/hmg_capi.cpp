@@ -2749,6 +2749,118 @@ int hmg_smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_ve
     HMG_END
 }
 
+// Where the five vectors of a level lie in HBM relative to each other moves the passes that stream five or six of them
+// at once by up to 8 % (tools/dev/placement_pick.py: three smoothing steps at config 3 take 61.2 ... 66.5 ms depending on
+// which of ten equal allocations plays which role; moving a vector INSIDE its allocation changes nothing, no rule in the
+// virtual addresses, another process on the same box draws another table -- the physical pages decide).  So the choice is
+// made by measurement, FFTW style: time this level's share of a V-cycle (the down and the up half, src/multigrid.jl:100-115,
+// with the pointer exchanges and folds the real cycle uses) for `trials` assignments of the 5 + `extra` blocks to the roles
+// x, b, r, p, Ap and keep the fastest.
+int hmg_level_tune_placement(hmg_grid *g, int level, int steps, hmg_vec **states, int extra, int trials, double *ms_out)
+{
+    HMG_TRY
+    need(g && g->has_op && states, "null argument or operator not set");
+    need(level >= 2 && level <= g->nlevels, "level must be 2..nlevels (level 1 has no smoother)");
+    need(steps >= 1, "steps must be positive");
+    need(extra >= 0 && extra <= 8, "extra must be 0..8");
+    need(trials >= 1 && trials <= 512, "trials must be 1..512");
+    hmg_vec **state = states + 5 * (level - 1);
+    hmg_vec **below = states + 5 * (level - 2);
+    for (int q = 0; q < 5; ++q) {
+        check_vec(g, level, state[q], "states[] (level)");
+        check_vec(g, level - 1, below[q], "states[] (level - 1)");
+        need(state[q]->own && state[q]->bytes == state[0]->bytes && state[q]->alloc_cells == state[0]->alloc_cells,
+             "the five vectors of the level must be hmg_vec_create'd vectors");
+        for (int p = 0; p < q; ++p) need(state[p] != state[q] && state[p]->d != state[q]->d, "the five vectors must be distinct");
+    }
+    hmg_ctx *c = g->ctx;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = state[0]->bytes;
+    const int64_t n = vec_len(state[0]);
+    std::vector<double *> blk;
+    for (int q = 0; q < 5; ++q) blk.push_back(state[q]->d);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<int> first = {0, 1, 2, 3, 4}, best = first;
+    auto assign = [&](const std::vector<int> &a) {
+        for (int q = 0; q < 5; ++q) state[q]->d = blk[(size_t)a[q]];
+    };
+    auto cleanup = [&](const std::vector<int> &keep) {      // the blocks no handle refers to go back
+        assign(keep);
+        (void)hipStreamSynchronize(c->stream);
+        for (size_t i = 0; i < blk.size(); ++i)
+            if (std::find(keep.begin(), keep.end(), (int)i) == keep.end()) (void)hipFree(blk[i]);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    double t_first = 0.0, t_best = 0.0;
+    try {
+        for (int e = 0; e < extra; ++e) blk.push_back(vec_alloc(c, bytes));
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        const int nb = (int)blk.size();
+        auto run = [&](const std::vector<int> &a) {
+            assign(a);
+            launch_fill(c->L, state[0]->d, n, 0.5);       // (r, p, Ap are written before they are read)
+            launch_fill(c->L, state[1]->d, n, 1.0);
+            HIPCHK(hipEventRecord(e0, c->stream));
+            // as hmg_vcycle runs them on its top level (each half exchanges the r and p pointers: restored by the pair; the
+            // coarse x stays the zero it is)
+            vcycle_down(g, level, steps, states, /*inside=*/true, /*x_zero=*/false, /*steps_next=*/2);
+            vcycle_up(g, level, steps, states, c->lean_post ? 1 : 0);
+            HIPCHK(hipEventRecord(e1, c->stream));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            return (double)ms;
+        };
+        (void)run(first);                                  // first touch of every kernel and table
+        uint64_t rng = 0x9E3779B97F4A7C15ull;              // (the same sequence on every rank: the halves may hold collectives)
+        auto next = [&]() {
+            rng ^= rng << 13;
+            rng ^= rng >> 7;
+            rng ^= rng << 17;
+            return rng;
+        };
+        t_best = 1e300;
+        for (int t = 0; t < trials; ++t) {
+            std::vector<int> a(nb);
+            for (int i = 0; i < nb; ++i) a[i] = i;
+            if (t > 0)
+                for (int i = 0; i < 5; ++i) std::swap(a[i], a[i + (int)(next() % (uint64_t)(nb - i))]);
+            a.resize(5);
+            const double ms = run(a);
+            if (t == 0) t_first = ms;
+            if (ms < t_best) {
+                t_best = ms;
+                best = a;
+            }
+        }
+        {   // a second look at both (always: every rank must issue the same number of calls): the handles keep what they
+            // had unless the gain is real
+            const double again_first = run(first), again_best = run(best);
+            t_first = std::min(t_first, again_first);
+            t_best = std::max(t_best, again_best);
+            if (!(t_best < 0.995 * t_first)) {
+                best = first;
+                t_best = t_first;
+            }
+        }
+    } catch (...) {
+        cleanup(first);
+        throw;
+    }
+    cleanup(best);
+    for (int q = 0; q < 5; ++q) {
+        HIPCHK(hipMemsetAsync(state[q]->d, 0, bytes, c->stream));
+        HIPCHK(hipMemsetAsync(below[q]->d, 0, sizeof(double) * (size_t)vec_len(below[q]), c->stream));
+    }
+    if (ms_out) {
+        ms_out[0] = t_first;
+        ms_out[1] = t_best;
+    }
+    HMG_END
+}
+
 int hmg_coarse_setup(hmg_grid *g)
 {
     HMG_TRY

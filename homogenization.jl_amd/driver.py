@@ -181,7 +181,7 @@ def checkerboard_problem(ctx, eltype, width: int, levels: int, seed: int = 0, va
 def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, smoothing_steps: int = 3,
                                 tolerance: float = 1e-4, xi=None, save=None, *, ctx=None, seed: int = 0,
                                 values=(1.0, 9.0), sigma_grid=None, x0=None, max_cycles: int = 1000, log=None,
-                                timings: dict | None = None):
+                                timings: dict | None = None, tune_placement: int = 0):
     """checkerboard_homogenization(n, type; refinements, smoothing_steps, tolerance, xi, save) -> sigma
     (src/examples/homogenized_coefficients.jl:174-343) with every level-vector operation on the device.
 
@@ -192,7 +192,9 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     (their columns are a prefix) instead of copying slices.  Returns (sigma, history) where history holds
     (k, cycle, norm(r), sigma + dsigma, |dsigma - dsigma_prev|) -- the three quantities the reference logs.
     `timings` (a dict) receives wall-clock seconds: "setup_s" (mesh, tables, level vectors, x0, right-hand side -- up to
-    the first V-cycle), "solve_s" (everything after), "vcycles", "outer_steps", "cells"."""
+    the first V-cycle), "solve_s" (everything after), "vcycles", "outer_steps", "cells".
+    `tune_placement` = T > 0: the finest level's five memory blocks are assigned to their roles by measurement
+    (api.tune_placement, T candidates; pays off for long runs only -- about 0.1 s per candidate at config 3)."""
     import time
     t_start = time.perf_counter()
     save_dir = "."
@@ -224,6 +226,10 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
     t_grid = time.perf_counter()
     states = [api.LevelState(implicit, i + 1) for i in range(total_grids)]
     top = states[-1]
+    if tune_placement:
+        tuned = api.tune_placement(implicit, ops, states, total_grids, smoothing_steps, trials=int(tune_placement))
+        if timings is not None:
+            timings["tune_ms"] = tuned
     ctx.sync()
     t_alloc = time.perf_counter()
     if x0 is None:

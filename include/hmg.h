@@ -161,6 +161,18 @@ int hmg_next_rhs(hmg_grid *grid, hmg_vec *x, hmg_vec *b);
 /* ---- fused fast path ------------------------------------------------------------------------ */
 /* smoothing_steps!(steps, implicit, ops, curr, k)            (src/multigrid.jl:46-71) */
 int hmg_smooth(hmg_grid *grid, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap);
+/* Optional, at setup: choose by measurement which memory block plays which role.  `states` as for hmg_vcycle (5 handles
+ * per level, level-major); the five hmg_vec_create'd vectors x, b, r, p, Ap of `level` >= 2 (LevelState,
+ * src/multigrid.jl:7-25) are tuned, those of level - 1 serve as the coarse side; operator set.  The passes that stream
+ * five or six finest-level vectors at once run up to 8 % slower or faster depending on where the blocks lie in HBM
+ * relative to each other -- a property of the physical pages, not of anything an address shows --
+ * so the library times this level's share of a V-cycle (hmg_vcycle_down + hmg_vcycle_up with `steps` smoothing steps)
+ * for `trials` assignments of the five blocks plus `extra` freshly allocated ones to the five roles, keeps the fastest
+ * (the handles' device pointers are exchanged; pointers obtained from hmg_vec_device_ptr before are stale), frees the
+ * blocks left over and zero-fills the vectors of both levels: CALL IT BEFORE THE VECTORS HOLD DATA.  ms_out (may be
+ * NULL): [0] time of the assignment the handles came with, [1] of the one they leave with.  Costs (trials + 3) x that
+ * share of a V-cycle; on a partitioned grid every rank must call it with the same arguments. */
+int hmg_level_tune_placement(hmg_grid *grid, int level, int steps, hmg_vec **states, int extra, int trials, double *ms_out);
 /* Coarse operator for the current sigma/lambda/boundary: replaces
  * cholesky(assemble_checkerboard(base, cond, lambda)[interior, interior])
  * (src/examples/homogenized_coefficients.jl:259-261) by a device-resident Jacobi-PCG. */

@@ -213,6 +213,17 @@ function vcycle!(implicit, base::HipBaseLevel, ops::Vector, levels::Vector{HipSt
     nothing
 end
 
+# Optional, once after the level states exist and before they hold data: which memory block plays x, b, r, p, Ap of
+# level k is chosen by timing that level's share of a V-cycle (include/hmg.h, hmg_level_tune_placement).
+function tune_placement!(ops::Vector, levels::Vector{HipState}, k::Int, steps = 3; trials = 8, extra = 2)
+    g = levels[1].x.grid
+    bind!(g, ops, k)
+    ms = zeros(Float64, 2)
+    check(ccall((:hmg_level_tune_placement, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Cint, Cint, Ptr{Float64}),
+                g.h, k, steps, handles(levels), extra, trials, ms))
+    (ms[1], ms[2])
+end
+
 # ---- driver right-hand sides and integrals (src/examples/homogenized_coefficients.jl:449-474, :592-713; src/implicit_fine_grid.jl:391-409)
 rhs_aξ∇v!(b::HipMatrix, ∂ϕ∂xᵢs, implicit, σs, ξ::SVector{dim,Float64}) where {dim} =
     (check(ccall((:hmg_rhs_axi_grad, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), b.grid.h, collect(ξ), b.h)); b)
