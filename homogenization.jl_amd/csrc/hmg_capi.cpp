@@ -1896,6 +1896,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_threads = 0;
     c->L.apply_mass_only = 0;
     c->L.apply_unblocked = 0;
+    c->L.persistent_waves = 32 * (int64_t)c->L.num_cu;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
     {
         LifetimeLock lock(lifetime_mutex());
@@ -1941,6 +1942,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_unblocked = value != 0;
     else if (n == "apply_wg512")
         ctx->L.apply_wg512 = value != 0;
+    else if (n == "persistent_waves")        // per CU; 0 = one workgroup per cell (dev / A-B knob)
+        ctx->L.persistent_waves = value > 0 ? value * (int64_t)ctx->L.num_cu : (int64_t)1 << 40;
     else if (n == "coarse_maxit")
         ctx->coarse_maxit = (int)value;
     else if (n == "coarse_check")

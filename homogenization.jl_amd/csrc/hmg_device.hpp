@@ -110,6 +110,7 @@ struct ApplyArgs {
     int64_t out_ld;        // column stride of out if it differs from the level's (slab restriction), else 0
     const int32_t *cell_list;   // optional: workgroup b works on cell cell_list[b] (ncell_list of them)
     int64_t ncell_list;
+    int64_t nwork;         // set by the launcher: work items (cells) of this launch -- one-wave workgroups loop over them
 };
 
 struct CoarseDev {
@@ -137,6 +138,8 @@ struct Launch {
     int apply_unblocked;  // 1: node-per-thread interior sweep instead of the register-blocked one (dev / A-B knob)
     int apply_wg512;      // 1 (default): cells that would take the 1024-thread register-blocked instantiation take the 512-thread one:
                           // three workgroups (three columns in flight) per CU instead of two
+    int64_t persistent_waves;   // grid of the one-wave apply instantiations (default 32 per CU: what is resident at once); they
+                          // loop over the cells.  Larger than the number of cells = one workgroup per cell
 };
 
 // out = (src ? src : 0) + alpha * A x, then (use_mask) zero Dirichlet DOFs.  src may alias out.

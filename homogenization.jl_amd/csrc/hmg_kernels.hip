@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 #define HMG_STAMP(i)                                                                     \
     do {   /* stamps behind the 2 * ncells reduction partials (full-grid launches only) */ \
         if (a.blockpart && !a.cell_list && tid == 0)                                     \
-            a.blockpart[2 * (size_t)gridDim.x + 8 * cell + (i)] = (double)wall_clock64(); \
+            a.blockpart[2 * (size_t)a.nwork + 8 * cell + (i)] = (double)wall_clock64(); \
     } while (0)
 #else
 #define HMG_STAMP(i)
@@ -55,7 +55,14 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     double *W = smem;
     double *xs = smem + WS + lv.lds_g0;
     const int tid = threadIdx.x;
-    const int64_t cell = a.cell_list ? (int64_t)a.cell_list[blockIdx.x] : (int64_t)blockIdx.x;
+    // One-wave workgroups (cells of up to 192 nodes) are PERSISTENT: a launch of 196 608 of them is bound by the rate at
+    // which waves can be started and by what every start repeats (kernel arguments, LDS allocation), not by the cells'
+    // work -- so the launcher starts as many as are resident at once and each walks its share of the cells.  (The body
+    // below is not indented for the loop: every other instantiation runs it exactly once.)
+    constexpr bool LOOP = NT == 64;
+    int64_t blk = blockIdx.x;
+    do {
+    const int64_t cell = a.cell_list ? (int64_t)a.cell_list[blk] : blk;
     const int nf = lv.nf;
     HMG_STAMP(0);
 
@@ -635,6 +642,12 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         }
     }
     HMG_STAMP(6);
+    if (LOOP) {
+        blk += gridDim.x;
+        if (blk >= a.nwork) break;
+        __syncthreads();                         // the next cell's table and image overwrite this one's
+    }
+    } while (LOOP);
 }
 
 // Slab variant for cells whose lattice image exceeds the LDS (level 7 in 3D: 374 KiB).  The cell is processed in
@@ -915,7 +928,11 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
     const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
     if (nblocks == 0) return;
     check_apply_bases<FUSED>(a, mesh);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, a);
+    ApplyArgs b = a;
+    b.nwork = nblocks;
+    // (NT == 64: persistent one-wave workgroups, see the kernel -- 32 waves per CU are resident)
+    const int64_t grid = NT == 64 ? std::min<int64_t>(nblocks, (int64_t)L.persistent_waves) : nblocks;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, b);
     check_launch();
 }
 
