@@ -259,6 +259,43 @@ def test_vcycle_matches_oracle(oracle, ctx, which, dim, n, levels):
     assert dbase.last_iterations() > 0
 
 
+@pytest.mark.parametrize("dim,n,grids,steps", [(2, 4, 4, 3), (3, 2, 3, 3), (3, 2, 4, 1), (3, 3, 5, 3)])
+def test_vcycle_matches_its_global_matrix_form(oracle, ctx, dim, n, grids, steps):
+    """The device against the SECOND statement of smoothing_steps! / vcycle! (tests/_global_form.py: global vectors, matrices
+    assembled on explicitly refined meshes, multiplicity-weighted dots, direct solve on level 1) -- no cell-local code of the
+    oracle takes part in the expected values; the oracle supplies only the mesh, the assembly and the node numbering.
+    x after each of two V-cycles: rel 1e-9 (the level-1 solve is PCG to 1e-13 here, a direct solve there); r: 1e-8."""
+    from _global_form import GlobalForm
+    O = oracle
+    lam = 1.0
+    rng = np.random.default_rng(23)
+    base = O.hypercube(dim, n)
+    sgrid = np.where(rng.random((n,) * dim + (dim,)) < 0.5, 1.0, 9.0)
+    cond = O.conductivity_per_element(base, sgrid, (0.0,) * dim)
+    implicit = O.ImplicitFineGrid.create(base, grids)                    # (node coordinates of the repeated nodes only)
+    G = GlobalForm(O, base, sgrid, lam, implicit, grids, dim)
+    g = hmg.ImplicitFineGrid(ctx, hmg.Mesh(base.nodes, base.elements + 1), grids)
+    A = hmg.L2PlusDivAGrad(g, lam, cond)
+    sts = [hmg.LevelState(g, i + 1) for i in range(grids)]
+    top = sts[-1]
+    top.x.rand(5)
+    hmg.broadcast_interfaces(top.x, g, grids)
+    hmg.apply_constraint(top.x, grids, g)
+    hmg.local_rhs(top.b, g)
+    gx = G.gather(top.x.to_host(), grids - 1)
+    gb = G.gather_sum(top.b.to_host(), grids - 1)
+    bl = hmg.BaseLevel(g)
+    for cycle in range(2):
+        hmg.vcycle(g, bl, [A] * grids, sts, grids, steps)
+        gx, gr = G.vcycle(grids - 1, gx, gb, steps)
+        dx, dr = G.gather(top.x.to_host(), grids - 1), G.gather(top.r.to_host(), grids - 1)
+        assert np.abs(dx - gx).max() <= 1e-9 * np.abs(gx).max(), (cycle, np.abs(dx - gx).max())
+        assert np.abs(dr - gr).max() <= 1e-8 * np.abs(gr).max(), (cycle, np.abs(dr - gr).max())
+    for s in sts:
+        s.close()
+    g.close()
+
+
 @pytest.mark.parametrize("dim,npts,levels", [(3, 60, 4), (2, 80, 5)])
 def test_unstructured_delaunay_mesh(oracle, ctx, dim, npts, levels):
     """A base mesh that is not a split cube lattice: Delaunay triangulation of random points (edges shared by

@@ -207,14 +207,10 @@ def test_multigrid_converges_to_direct_solution(oracle, dim, n, grids):
 
 @pytest.mark.parametrize("dim,n,grids,steps", [(2, 4, 3, 3), (2, 3, 4, 1), (3, 2, 3, 3)])
 def test_vcycle_equals_its_global_matrix_form(oracle, dim, n, grids, steps):
-    """Second independent statement of smoothing_steps! / vcycle! (src/multigrid.jl:46-119): the same iteration written
-    on GLOBAL vectors with explicitly assembled matrices -- refine_uniformly + assemble_checkerboard per level (the recipe
-    of checkerboard_hypercube_full, ...homogenized_coefficients.jl:729-759), interpolation matrices built from the node
-    coordinates, and the reference's duplicate-counting dot products (src/multigrid.jl:54,64,67: a node shared by m cells
-    counts m times) as multiplicity-weighted sums.  None of the cell-local machinery (lattice tables, interface sums,
-    per-cell transfers, copy_to_base / distribute) takes part, so agreement to rounding pins all of it at once."""
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as spla
+    """Second independent statement of smoothing_steps! / vcycle! (src/multigrid.jl:46-119): tests/_global_form.py -- the same
+    iteration on GLOBAL vectors with explicitly assembled matrices per level and multiplicity-weighted dot products.  None of
+    the cell-local machinery takes part, so agreement to rounding pins all of it at once."""
+    from _global_form import GlobalForm
     O = oracle
     lam = 1.0
     rng = np.random.default_rng(11)
@@ -232,84 +228,12 @@ def test_vcycle_equals_its_global_matrix_form(oracle, dim, n, grids, steps):
     O.broadcast_interfaces(top.x, implicit, grids)
     O.apply_constraint(top.x, grids, constraint, implicit)
     O.local_rhs(top.b, implicit)
-
-    # ---- the global side --------------------------------------------------------------------------------------------
-    w = np.array([1, 1 << 20, 1 << 40][:dim])
-    key = lambda p: np.round(np.asarray(p) * 4096).astype(np.int64) @ w       # coordinates are exact dyadics
-    meshes, A, inner, mapping, mult = [], [], [], [], []
-    for l in range(grids):
-        m = O.refine_uniformly(base, times=l) if l else base
-        m.elements = O.sort_element_nodes(m.elements)
-        meshes.append(m)
-        A.append(O.assemble_checkerboard(m, O.conductivity_per_element(m, sgrid, (0.0,) * dim), lam).tocsr())
-        mask = np.zeros(m.nnodes(), dtype=bool)
-        mask[O.list_interior_nodes(m)] = True
-        inner.append(mask)
-        tk = key(m.nodes)
-        order = np.argsort(tk)
-        rep = implicit.construct_full_grid(l + 1).reshape(-1, dim)           # repeated nodes, cell-major
-        pos = np.searchsorted(tk[order], key(rep))
-        assert np.all(tk[order][pos] == key(rep))
-        mapping.append(order[pos])
-        mult.append(np.bincount(order[pos], minlength=m.nnodes()).astype(np.float64))
-    interp = [None]
-    for l in range(1, grids):                                                 # fine node = coarse node, or midpoint of a coarse edge
-        coarse, fine = meshes[l - 1], meshes[l]
-        ck = {int(k): i for i, k in enumerate(key(coarse.nodes))}
-        mid = {}
-        for el in coarse.elements:
-            for a in range(len(el)):
-                for b in range(a + 1, len(el)):
-                    mid[int(key(0.5 * (coarse.nodes[el[a]] + coarse.nodes[el[b]])))] = (int(el[a]), int(el[b]))
-        rows, cols, vals = [], [], []
-        for i, k in enumerate(key(fine.nodes)):
-            if int(k) in ck:
-                rows.append(i); cols.append(ck[int(k)]); vals.append(1.0)
-            else:
-                a, b = mid[int(k)]
-                rows += [i, i]; cols += [a, b]; vals += [0.5, 0.5]
-        interp.append(sp.csr_matrix((vals, (rows, cols)), shape=(fine.nnodes(), coarse.nnodes())))
-
-    def gather(local, l):                                                     # one global vector from consistent copies
-        g = np.zeros(meshes[l].nnodes())
-        flat = local.reshape(-1, order="F")
-        g[mapping[l]] = flat
-        assert np.array_equal(g[mapping[l]], flat)                           # all copies of a node agree
-        return g
-
-    def smooth(l, x, b, nsteps):
-        mdot = lambda u, v: float(np.dot(mult[l] * u, v))
-        r = np.where(inner[l], b - A[l] @ x, 0.0)
-        p = r.copy()
-        rs = mdot(r, r)
-        for _ in range(nsteps):
-            Ap = np.where(inner[l], A[l] @ p, 0.0)
-            alpha = rs / mdot(p, Ap)
-            x = x + alpha * p
-            r = r - alpha * Ap
-            rs_new = mdot(r, r)
-            p = r + (rs_new / rs) * p
-            rs = rs_new
-        return x, r
-
-    def vcycle(l, x, b, nsteps):
-        if l == 0:
-            x = np.zeros_like(x)
-            idx = np.flatnonzero(inner[0])
-            x[idx] = spla.spsolve(A[0][idx][:, idx].tocsc(), b[idx])
-            return x, None
-        x, _ = smooth(l, x, b, nsteps)
-        r = np.where(inner[l], b - A[l] @ x, 0.0)
-        xc, _ = vcycle(l - 1, np.zeros(meshes[l - 1].nnodes()), interp[l].T @ r, 2)   # `steps` is not forwarded (:109)
-        x = x + interp[l] @ xc
-        return smooth(l, x, b, nsteps)
-
-    gx = gather(top.x, grids - 1)
-    gb = np.zeros(meshes[-1].nnodes())
-    np.add.at(gb, mapping[-1], top.b.reshape(-1, order="F"))                  # the global load = sum of the local ones
+    G = GlobalForm(O, base, sgrid, lam, implicit, grids, dim)
+    gx = G.gather(top.x, grids - 1)
+    gb = G.gather_sum(top.b, grids - 1)
     for cycle in range(2):
         O.vcycle(implicit, base_level, ops, states, grids, steps)
-        gx, gr = vcycle(grids - 1, gx, gb, steps)
-        ox, orr = gather(top.x, grids - 1), gather(top.r, grids - 1)
+        gx, gr = G.vcycle(grids - 1, gx, gb, steps)
+        ox, orr = G.gather(top.x, grids - 1), G.gather(top.r, grids - 1)
         assert np.abs(ox - gx).max() <= 1e-11 * np.abs(gx).max(), (cycle, np.abs(ox - gx).max())
         assert np.abs(orr - gr).max() <= 1e-10 * max(np.abs(gr).max(), 1e-300), (cycle, np.abs(orr - gr).max())
