@@ -296,6 +296,48 @@ def test_vcycle_matches_its_global_matrix_form(oracle, ctx, dim, n, grids, steps
     g.close()
 
 
+@pytest.mark.parametrize("dim,width,levels,radius", [(2, 6, 4, 2), (3, 4, 3, 1), (3, 4, 5, 1)])
+def test_driver_integrals_equal_textbook_fem(oracle, ctx, dim, width, levels, radius):
+    """The device's right-hand sides and integrals (hmg_rhs_axi_grad, hmg_next_rhs, hmg_integrate) against textbook P1 elements
+    on the explicitly refined mesh (tests/_textbook_fem.py): no reference-element table of the oracle takes part in the
+    expected values.  1e-11."""
+    from _textbook_fem import driver_setting
+    O = oracle
+    base, cond, implicit, T, a_fine, inside, mapping, nint, rng = driver_setting(O, dim, width, levels, radius)
+    xi = rng.standard_normal(dim)
+    nf, ne = implicit.nf(levels), base.nelements()
+    lam = 0.37
+    g = hmg.ImplicitFineGrid(ctx, hmg.Mesh(base.nodes, base.elements + 1), levels)
+    A = hmg.L2PlusDivAGrad(g, lam, cond)
+    A._bind()
+    gather_sum = lambda loc: np.bincount(mapping, weights=loc.reshape(-1, order="F"), minlength=len(T.nodes))
+
+    def consistent(seed):
+        v = np.asfortranarray(np.random.default_rng(seed).standard_normal((nf, ne)))
+        O.broadcast_interfaces(v, implicit, levels)
+        gl = np.zeros(len(T.nodes))
+        gl[mapping] = v.reshape(-1, order="F")
+        return hmg.DeviceMatrix(g, levels).from_host(v), gl
+
+    b = hmg.DeviceMatrix(g, levels)
+    hmg.rhs_axi_grad_v(b, g, xi)
+    F = T.load(a_fine, xi)
+    assert np.abs(gather_sum(b.to_host()) - F).max() <= 1e-11 * np.abs(F).max()
+    v0, g0 = consistent(1)
+    v1, g1 = consistent(2)
+    want = float(np.dot(g0, T.load(a_fine, xi, inside))) + T.mass_quadratic(g0, g0, inside)
+    assert abs(hmg.integrate_first_term(v0, g, nint, xi, b=b) - want) <= 1e-11 * abs(want)
+    want = T.mass_quadratic(g0 + g1, g0, inside)
+    assert abs(hmg.integrate_terms(v0, v1, g, nint) - want) <= 1e-11 * abs(want)
+    assert abs(hmg.integrate_area(v0, g, nint) - float(np.dot(T.vol, inside))) <= 1e-12 * nint
+    hmg.next_rhs(b, v0, g)
+    want = lam * T.mass_apply(g0)
+    assert np.abs(gather_sum(b.to_host()) - want).max() <= 1e-11 * np.abs(want).max()
+    for v in (b, v0, v1):
+        v.close()
+    g.close()
+
+
 @pytest.mark.parametrize("dim,npts,levels", [(3, 60, 4), (2, 80, 5)])
 def test_unstructured_delaunay_mesh(oracle, ctx, dim, npts, levels):
     """A base mesh that is not a split cube lattice: Delaunay triangulation of random points (edges shared by

@@ -237,3 +237,43 @@ def test_vcycle_equals_its_global_matrix_form(oracle, dim, n, grids, steps):
         ox, orr = G.gather(top.x, grids - 1), G.gather(top.r, grids - 1)
         assert np.abs(ox - gx).max() <= 1e-11 * np.abs(gx).max(), (cycle, np.abs(ox - gx).max())
         assert np.abs(orr - gr).max() <= 1e-10 * max(np.abs(gr).max(), 1e-300), (cycle, np.abs(orr - gr).max())
+
+
+@pytest.mark.parametrize("dim,width,levels,radius", [(2, 6, 4, 2), (3, 4, 3, 1)])
+def test_driver_integrals_equal_textbook_fem(oracle, dim, width, levels, radius):
+    """rhs_a xi grad v!, next_rhs!, integrate_first_term / _terms / _area (src/examples/homogenized_coefficients.jl:449-474,
+    592-713) against textbook P1 elements on the explicitly refined mesh (tests/_textbook_fem.py: cell volumes and hat-function
+    gradients only).  Unit cubes (|J| = 1), as in every use the reference makes of them."""
+    O = oracle
+    from _textbook_fem import driver_setting
+    base, cond, implicit, T, a_fine, inside, mapping, nint, rng = driver_setting(O, dim, width, levels, radius)
+    xi = rng.standard_normal(dim)
+    nf, ne = implicit.nf(levels), base.nelements()
+    fine_ref = implicit.reference.levels[-1]
+    dphis, mass = O.partial_derivatives_functionals(fine_ref), O.mass_matrix(fine_ref)
+    gather_sum = lambda loc: np.bincount(mapping, weights=loc.reshape(-1, order="F"), minlength=len(T.nodes))
+
+    def consistent(seed):
+        v = np.asfortranarray(np.random.default_rng(seed).standard_normal((nf, ne)))
+        O.broadcast_interfaces(v, implicit, levels)
+        g = np.zeros(len(T.nodes))
+        g[mapping] = v.reshape(-1, order="F")
+        return v, g
+
+    b = np.zeros((nf, ne), order="F")
+    O.rhs_axi_grad_v(b, dphis, implicit, cond, xi)
+    F = T.load(a_fine, xi)
+    assert np.abs(gather_sum(b) - F).max() <= 1e-12 * np.abs(F).max()
+    v0, g0 = consistent(1)
+    v1, g1 = consistent(2)
+    want = float(np.dot(g0, T.load(a_fine, xi, inside))) + T.mass_quadratic(g0, g0, inside)
+    got = O.integrate_first_term(v0, dphis, implicit, nint, mass, cond, xi)
+    assert abs(got - want) <= 1e-11 * abs(want)
+    want = T.mass_quadratic(g0 + g1, g0, inside)
+    got = O.integrate_terms(v0, v1, implicit, nint, mass)
+    assert abs(got - want) <= 1e-11 * abs(want)
+    assert abs(O.integrate_area(mass, implicit, nint) - float(np.dot(T.vol, inside))) <= 1e-12 * nint
+    lam = 0.37
+    O.next_rhs(b, v0, implicit, mass, lam)
+    want = lam * T.mass_apply(g0)
+    assert np.abs(gather_sum(b) - want).max() <= 1e-12 * np.abs(want).max()
