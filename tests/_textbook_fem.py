@@ -72,3 +72,40 @@ def driver_setting(O, dim, width, levels, radius, seed=3):
     nint = O.find_elements_in_radius(base, radius)
     assert 0 < nint < base.nelements()
     return base, cond, implicit, T, a_fine, inside, mapping, nint, rng
+
+
+def converged_first_term(O, dim, sigma_grid, xi, refinements, lam=1.0):
+    """What outer step 0 of checkerboard_homogenization (src/examples/homogenized_coefficients.jl:174-343, n = 0: box radius
+    1, boundary layer 4, 10^dim unit cubes) converges to, by a sparse direct (large 3D cases: conjugate-gradient, 1e-14) solve of (lam M + K_a) v = F on the explicitly
+    refined mesh with v = 0 on the boundary:  sigma_0 = (v . F_box + v^T M_box v) / |box|."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    total_radius, box_radius = 5, 1
+    width = 2 * total_radius
+    base = O.order_nodes_and_elements_by_magnitude(O.hypercube(dim, width, origin=(-float(total_radius),) * dim))
+    fine = O.refine_uniformly(base, times=refinements)
+    T = TextbookP1(fine.nodes, fine.elements)
+    a = O.conductivity_per_element(fine, sigma_grid, (total_radius + 1.0,) * dim)
+    nv = T.elements.shape[1]
+    # stiffness with the diagonal conductivity a_K, mass
+    ag = T.grad * a[:, None, :]
+    Kloc = np.einsum("kid,kjd->kij", ag, T.grad) * T.vol[:, None, None]
+    Mloc = (np.ones((nv, nv)) + np.eye(nv))[None, :, :] * (T.vol / (nv * (nv + 1)))[:, None, None]
+    rows = np.repeat(T.elements, nv, axis=1).ravel()
+    cols = np.tile(T.elements, (1, nv)).ravel()
+    n = len(T.nodes)
+    A = sp.csr_matrix(((Kloc + lam * Mloc).ravel(), (rows, cols)), shape=(n, n))
+    F = T.load(a, xi)
+    interior = np.flatnonzero(np.abs(T.nodes).max(axis=1) < total_radius - 1e-9)
+    v = np.zeros(n)
+    Aii = A[interior][:, interior].tocsr()
+    if len(interior) <= 20000:
+        v[interior] = spla.spsolve(Aii.tocsc(), F[interior])
+    else:                                                             # (3D fill-in: conjugate gradients to 1e-14 instead)
+        d = Aii.diagonal()
+        prec = spla.LinearOperator(Aii.shape, matvec=lambda r: r / d)
+        sol, info = spla.cg(Aii, F[interior], rtol=1e-14, atol=0.0, maxiter=20000, M=prec)
+        assert info == 0
+        v[interior] = sol
+    inside = (np.abs(T.centers).max(axis=1) <= box_radius).astype(np.float64)
+    return (float(np.dot(v, T.load(a, xi, inside))) + T.mass_quadratic(v, v, inside)) / float(np.dot(T.vol, inside))

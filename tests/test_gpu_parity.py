@@ -338,6 +338,23 @@ def test_driver_integrals_equal_textbook_fem(oracle, ctx, dim, width, levels, ra
     g.close()
 
 
+@pytest.mark.parametrize("dim,refinements", [(2, 3), (3, 1), (3, 2)])
+def test_driver_converges_to_the_direct_fem_answer(oracle, ctx, dim, refinements):
+    """driver.checkerboard_homogenization with n = 0 (one outer step) on the device, run to a tight tolerance, against a sparse
+    direct solve of the same boundary value problem on the explicitly refined mesh (tests/_textbook_fem.py): mesh ordering,
+    conductivity lookup, right-hand side, V-cycle, integrals and the sigma formula in one number.  1e-8."""
+    from _textbook_fem import converged_first_term
+    from homogenization_jl_amd import driver
+    rng = np.random.default_rng(8)
+    sgrid = np.where(rng.random((10,) * dim + (dim,)) < 0.5, 1.0, 9.0)
+    xi = rng.standard_normal(dim)
+    xi /= np.linalg.norm(xi)
+    sigma, hist = driver.checkerboard_homogenization(0, hmg.Tet64 if dim == 3 else hmg.Tri64, refinements=refinements, tolerance=1e-12,
+                                                     xi=xi, sigma_grid=sgrid, ctx=ctx, max_cycles=60)
+    want = converged_first_term(oracle, dim, sgrid, xi, refinements)
+    assert abs(sigma - want) <= 1e-8 * abs(want), (sigma, want, len(hist))
+
+
 @pytest.mark.parametrize("dim,npts,levels", [(3, 60, 4), (2, 80, 5)])
 def test_unstructured_delaunay_mesh(oracle, ctx, dim, npts, levels):
     """A base mesh that is not a split cube lattice: Delaunay triangulation of random points (edges shared by

@@ -277,3 +277,21 @@ def test_driver_integrals_equal_textbook_fem(oracle, dim, width, levels, radius)
     O.next_rhs(b, v0, implicit, mass, lam)
     want = lam * T.mass_apply(g0)
     assert np.abs(gather_sum(b) - want).max() <= 1e-12 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("dim,refinements", [(2, 3), (3, 1)])
+def test_driver_converges_to_the_direct_fem_answer(oracle, dim, refinements):
+    """checkerboard_homogenization with n = 0 (one outer step; src/examples/homogenized_coefficients.jl:174-343) run to a tight
+    tolerance must land on what a sparse direct solve of the same boundary value problem on the explicitly refined mesh gives
+    (tests/_textbook_fem.py) -- mesh ordering, conductivity lookup, right-hand side, V-cycle, integrals and the sigma formula
+    in one number."""
+    from _textbook_fem import converged_first_term
+    O = oracle
+    rng = np.random.default_rng(8)
+    sgrid = np.where(rng.random((10,) * dim + (dim,)) < 0.5, 1.0, 9.0)
+    xi = rng.standard_normal(dim)
+    xi /= np.linalg.norm(xi)
+    sigma, hist = O.checkerboard_homogenization(n=0, dim=dim, refinements=refinements, tolerance=1e-12, xi=xi, sigma_grid=sgrid,
+                                                max_cycles=60)
+    want = converged_first_term(O, dim, sgrid, xi, refinements)
+    assert abs(sigma - want) <= 1e-9 * abs(want), (sigma, want, len(hist))
