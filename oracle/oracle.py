@@ -22,6 +22,12 @@ by re-stating the reference's own known-answer tests against it (tests/test_orac
   test/generated_grids.jl:4-10          hypercube(Tet, 20): sorted, 21^3 nodes, 6*20^3 cells
 Not pinned by any reference test (none exists): smoothing_steps!/vcycle!/coarse solve and the
 driver; those are restated from the source only ("parity unpinned" for those rows).
+What stands in for a reference-held pin there are statements that share no code path with this file's
+cell-local machinery (tests/_global_form.py, tests/_textbook_fem.py): the V-cycle written on global vectors
+with matrices assembled on explicitly refined meshes and multiplicity-weighted dots (1e-11), the driver's
+right-hand sides and integrals from textbook P1 elements (1e-11), and the converged n = 0 driver against a
+direct solve of the boundary value problem (1e-9).  They pin the EXECUTION of the algorithm; which algorithm
+the reference runs (its dots, its `steps`, its sigma formula) is pinned by the line citations alone.
 """
 from __future__ import annotations
 
