@@ -259,7 +259,7 @@ def test_vcycle_matches_oracle(oracle, ctx, which, dim, n, levels):
     assert dbase.last_iterations() > 0
 
 
-@pytest.mark.parametrize("dim,n,grids,steps", [(2, 4, 4, 3), (3, 2, 3, 3), (3, 2, 4, 1), (3, 3, 5, 3)])
+@pytest.mark.parametrize("dim,n,grids,steps", [(2, 4, 4, 3), (3, 2, 3, 3), (3, 2, 4, 1), (3, 3, 5, 3), (3, 2, 6, 3)])
 def test_vcycle_matches_its_global_matrix_form(oracle, ctx, dim, n, grids, steps):
     """The device against the SECOND statement of smoothing_steps! / vcycle! (tests/_global_form.py: global vectors, matrices
     assembled on explicitly refined meshes, multiplicity-weighted dots, direct solve on level 1) -- no cell-local code of the
