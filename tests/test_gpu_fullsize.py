@@ -220,6 +220,40 @@ def test_exact_savings_leave_x_and_r_untouched_full_size(prob):
             st.close()
 
 
+def test_vcycle_is_reproducible_bit_for_bit_full_size(prob):
+    """Race freedom by construction (one work-item group per shared entity, copies summed in ascending cell order, reductions
+    in fixed trees): three V-cycles from the same x0 and b, run three times -- on fresh level vectors each time (other memory
+    blocks), once with the blocks' roles re-assigned by hmg_level_tune_placement -- leave x and r equal to the last bit on all
+    1.29e9 entries."""
+    ctx, g, A = prob
+    base = hmg.BaseLevel(g)
+    xi = driver.random_unit_vec(3)
+    keep = None
+    for run in range(3):
+        states = [hmg.LevelState(g, i + 1) for i in range(L)]
+        if run == 2:
+            before, after = hmg.tune_placement(g, [A] * L, states, L, 3, trials=3, extra=1)
+            assert after <= before
+        top = states[-1]
+        top.x.rand(33)
+        hmg.broadcast_interfaces(top.x, g, L)
+        hmg.apply_constraint(top.x, L, g)
+        hmg.rhs_axi_grad_v(top.b, g, xi)
+        for _ in range(3):
+            hmg.vcycle(g, base, [A] * L, states, L, 3)
+        if keep is None:
+            keep = (top.x.copy(), top.r.copy())
+            assert hmg.dot(keep[0], keep[0]) > 0.0
+        else:
+            hmg.axpy(-1.0, keep[0], top.x)
+            hmg.axpy(-1.0, keep[1], top.r)
+            assert hmg.dot(top.x, top.x) == 0.0 and hmg.dot(top.r, top.r) == 0.0, run
+        for st in states:
+            st.close()
+    for v in keep:
+        v.close()
+
+
 def test_interface_sum_constraint_duplicates_match_oracle_full_size(prob, oracle):
     """broadcast_interfaces!, apply_constraint! and zero_out_all_but_one! (src/implicit_fine_grid.jl:94-386) on all
     1.29e9 entries of a config-3 level-6 vector against the oracle run on the same 10 GB array -- integer / index work plus
