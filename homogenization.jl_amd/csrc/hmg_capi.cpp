@@ -312,7 +312,7 @@ struct hmg_grid {
     int64_t stage_cap = 0;
     DevBuf<double> own_stage;
     bool overlap = true;
-    DevBuf<int32_t> d_cells_cut, d_cells_inner;
+    DevBuf<int32_t> d_cells_cut, d_cells_inner, d_cell_perm;
     void *ex_user = nullptr;
     double *ex_buf = nullptr;
     int64_t ex_cap = 0;
@@ -445,6 +445,20 @@ void upload_mesh(hmg_grid *g)
     d.cells_inner = g->d_cells_inner.p;
     d.ncells_cut = (int64_t)M.cells_cut.size();
     d.ncells_inner = (int64_t)M.cells_inner.size();
+    {   // XCD-aware cell order of the full-grid apply launches (option cell_order): workgroups are dispatched round-robin over
+        // the 8 XCDs (workgroup b -> XCD b % 8), so with cell = b every XCD's L2 sees every eighth column of every vector.  Here
+        // XCD x walks the x-th contiguous eighth of the cells instead: -0.7 ... -1.3 ms per V-cycle (2, 4, 16 regions: -0.1 ... -0.4;
+        // 64 regions or runs of 8 cells per XCD: slower; profiles/r03_experiments.txt).  A performance hint only: any mapping is correct.
+        const int64_t n = M.ncells, len = (n + 7) / 8;
+        std::vector<int32_t> perm((size_t)n);
+        int64_t k = 0;
+        for (int64_t b = 0; k < n; ++b) {
+            const int64_t pos = b / 8, c = (b % 8) * len + pos;
+            if (pos < len && c < n) perm[(size_t)k++] = (int32_t)c;
+        }
+        g->d_cell_perm.upload(perm, s);
+        d.cell_perm = g->d_cell_perm.p;
+    }
     d.ncut_edge_groups = M.ncut_edge_groups;
     d.ncut_node_groups = M.ncut_node_groups;
     d.ncut_face_pairs = M.ncut_face_pairs;
@@ -1897,6 +1911,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_mass_only = 0;
     c->L.apply_unblocked = 0;
     c->L.persistent_waves = 32 * (int64_t)c->L.num_cu;
+    c->L.cell_order = 1;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
     {
         LifetimeLock lock(lifetime_mutex());
@@ -1942,6 +1957,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_unblocked = value != 0;
     else if (n == "apply_wg512")
         ctx->L.apply_wg512 = value != 0;
+    else if (n == "cell_order")            // 1 = default: XCD-aware cell order of the register-blocked full-grid apply launches
+        ctx->L.cell_order = value != 0;
     else if (n == "persistent_waves")        // per CU; 0 = one workgroup per cell (dev / A-B knob)
         ctx->L.persistent_waves = value > 0 ? value * (int64_t)ctx->L.num_cu : (int64_t)1 << 40;
     else if (n == "coarse_maxit")

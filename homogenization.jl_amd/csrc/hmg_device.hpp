@@ -75,6 +75,7 @@ struct MeshDev {
     int64_t ncut_edge_groups, ncut_node_groups;   // leading groups of the edge / node CSR that are cut
     int64_t ncut_face_pairs;                      // leading face pairs that count as cut (rehearsal partitions only, else 0)
     const int32_t *cells_cut, *cells_inner;       // partitioned grids: cell lists for the overlapped exchange
+    const int32_t *cell_perm;                     // option cell_order: workgroup b of a full-grid register-blocked apply works on cell_perm[b]
     int64_t ncells_cut, ncells_inner;
     const uint8_t *mult;         // 16 per cell: number of copies of each entity (bit order of the masks)
     double *blockpart;           // 2 per cell: scratch for the fused apply's block sums
@@ -138,6 +139,7 @@ struct Launch {
     int apply_unblocked;  // 1: node-per-thread interior sweep instead of the register-blocked one (dev / A-B knob)
     int apply_wg512;      // 1 (default): cells that would take the 1024-thread register-blocked instantiation take the 512-thread one:
                           // three workgroups (three columns in flight) per CU instead of two
+    int cell_order;       // 1 (default): full-grid register-blocked apply launches walk the cells XCD by XCD (MeshDev::cell_perm)
     int64_t persistent_waves;   // grid of the one-wave apply instantiations (default 32 per CU: what is resident at once); they
                           // loop over the cells.  Larger than the number of cells = one workgroup per cell
 };

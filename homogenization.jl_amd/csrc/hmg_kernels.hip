@@ -930,6 +930,10 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
     check_apply_bases<FUSED>(a, mesh);
     ApplyArgs b = a;
     b.nwork = nblocks;
+    if (L.cell_order && RB && !a.cell_list && !a.ncells_prefix && mesh.cell_perm) {
+        b.cell_list = mesh.cell_perm;              // (XCD x walks the x-th eighth of the cells, see upload_mesh)
+        b.ncell_list = nblocks;
+    }
     // (NT == 64: persistent one-wave workgroups, see the kernel -- 32 waves per CU are resident)
     const int64_t grid = NT == 64 ? std::min<int64_t>(nblocks, (int64_t)L.persistent_waves) : nblocks;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, L.stream, lv, mesh.coef, mesh.dmask, b);
