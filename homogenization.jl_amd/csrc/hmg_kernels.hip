@@ -952,7 +952,12 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
         if (nblocks == 0) return;
         check_apply_bases<FUSED>(a, mesh);
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, a,
+        ApplyArgs b = a;
+        if (L.cell_order && !a.cell_list && !a.ncells_prefix && mesh.cell_perm) {   // (XCD-aware cell order, as in launch_apply_generic)
+            b.cell_list = mesh.cell_perm;
+            b.ncell_list = nblocks;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(1024), bytes, L.stream, lv, mesh.coef, mesh.dmask, b,
                            mesh.slab);
         check_launch();
         return;
