@@ -181,7 +181,7 @@ def test_vcycle_contracts_full_size(prob):
     assert all(b < 0.7 * a for a, b in zip(norms, norms[1:])), norms
 
 
-EXACT = ("lean_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict", "zero_entry")
+EXACT = ("lean_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict", "zero_entry", "cell_order")
 
 
 def test_exact_savings_leave_x_and_r_untouched_full_size(prob):
@@ -189,8 +189,8 @@ def test_exact_savings_leave_x_and_r_untouched_full_size(prob):
     lazy_dead, fold_x: work whose results the reference's own control flow overwrites before reading), r taken as p by
     exchanging handles (swap_rp), the prolongation folded into the post-smoother's first residual (fold_prolong,
     prolong_in_image), the face sums of A p formed inside the r-update (fold_faces), the restriction in the local residual's epilogue
-    (fold_restrict), coarse levels whose zero initial guess is never written (zero_entry): x and r of the finest level after two
-    V-cycles are equal to the last bit."""
+    (fold_restrict), coarse levels whose zero initial guess is never written (zero_entry), the XCD-aware order in which the apply
+    launches walk the cells (cell_order): x and r of the finest level after two V-cycles are equal to the last bit."""
     ctx, g, A = prob
     base = hmg.BaseLevel(g)
     res = []

@@ -776,7 +776,7 @@ def test_handles_may_be_destroyed_in_any_order(oracle):
 
 
 EXACT_OPTIONS = ("lean_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict",
-                 "zero_entry")
+                 "zero_entry", "cell_order")
 
 
 @pytest.mark.parametrize("dim,n,levels", [(3, 4, 5), (3, 2, 6), (2, 8, 5)])
