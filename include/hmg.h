@@ -68,7 +68,10 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * coarse right-hand side is the stand-alone restriction's to the last bit), "zero_entry" (1 = default: inside hmg_vcycle a
  * coarse level's zero initial guess is never written -- its first residual is the constrained copy of b and the local
  * residual that carries both pending x-updates does not read x), "fold_faces" (1 = default: the face part of A p's
- * interface sum rides in the CG r-update), "overlap_min_doubles" / "comm_rehearsal" (multi-GPU, below),
+ * interface sum rides in the CG r-update), "cell_order" (1 = default: the full-grid apply launches of cells of >= 969 nodes
+ * walk the cells XCD by XCD -- workgroups are dispatched round-robin over the eight XCDs, XCD x takes the x-th contiguous eighth
+ * of the cells; a performance hint, results unchanged), "persistent_waves" (one-wave apply workgroups per CU that walk the
+ * cells of the small levels; default 32, 0 = one workgroup per cell), "overlap_min_doubles" / "comm_rehearsal" (multi-GPU, below),
  * "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
  * hmg_vec_create of the same size -- re-allocating freed device memory costs ~35 ms per GB here; 0 = free at once and
  * release what is held; hmg_ctx_destroy releases it too), "coarse_maxit", "coarse_check",
