@@ -439,8 +439,24 @@ void upload_mesh(hmg_grid *g)
     d.dupmask = g->d_dupmask.p;
     d.mult = g->d_mult.p;
     d.blockpart = g->d_blockpart.p;
-    g->d_cells_cut.upload(M.cells_cut, s);
-    g->d_cells_inner.upload(M.cells_inner, s);
+    {   // (the cell lists of the overlapped exchange in the XCD-aware order too: workgroup b -> XCD b % 8 walks the
+        //  (b % 8)-th contiguous eighth of the list, see cell_perm below)
+        const char *env = std::getenv("HMG_XCD_LISTS");          // (dev knob: 0 = the lists as the partition analysis made them)
+        const bool on = !(env && env[0] == '0');
+        auto xcd_order = [on](const std::vector<int32_t> &v) {
+            if (!on) return v;
+            const int64_t n = (int64_t)v.size(), len = (n + 7) / 8;
+            std::vector<int32_t> o((size_t)n);
+            int64_t k = 0;
+            for (int64_t b = 0; k < n; ++b) {
+                const int64_t pos = b / 8, c = (b % 8) * len + pos;
+                if (pos < len && c < n) o[(size_t)k++] = v[(size_t)c];
+            }
+            return o;
+        };
+        g->d_cells_cut.upload(xcd_order(M.cells_cut), s);
+        g->d_cells_inner.upload(xcd_order(M.cells_inner), s);
+    }
     d.cells_cut = g->d_cells_cut.p;
     d.cells_inner = g->d_cells_inner.p;
     d.ncells_cut = (int64_t)M.cells_cut.size();
