@@ -21,6 +21,7 @@ ap.add_argument("--buffers", type=int, default=10)
 ap.add_argument("--trials", type=int, default=40)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--order", default="after", choices=["after", "before"], help="buffers allocated after / before the grid")
+ap.add_argument("--alloc-gib", type=float, default=0.0, help="size of every allocation in GiB (0: the vector's size + 4 KB) -- does a rounder size change the spread?")
 args = ap.parse_args()
 
 ctx = hmg.Context(0)
@@ -35,7 +36,9 @@ if args.order == "before":
 base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, args.width, L, seed=0)
 nbytes = 8 * g.ld(L) * g.ncells()
 if bufs is None:
-    bufs = [torch.empty(nbytes + 4096, dtype=torch.uint8, device="cuda:0") for _ in range(NB)]
+    asize = int(args.alloc_gib * 2**30) if args.alloc_gib else nbytes + 4096
+    assert asize >= nbytes
+    bufs = [torch.empty(asize, dtype=torch.uint8, device="cuda:0") for _ in range(NB)]
 assert bufs[0].numel() >= nbytes
 torch.cuda.synchronize()
 ptrs = [b.data_ptr() for b in bufs]
