@@ -301,6 +301,11 @@ struct hmg_grid {
     int64_t part_nnodes = 0, part_ncells = 0;
     DevBuf<int32_t> d_nodes_g, d_owned, d_cells_gnode;
     CutKind cut[3];   // faces, edges, nodes
+    // Number of cut entities per kind OVER ALL RANKS, agreed once per partition analysis (agree_on_cut): what the overlap
+    // decision of apply_then_sum looks at.  (CutKind::nglobal is rank-local after a halo-only analysis.)  -1: no agreement
+    // possible (no scalar_sum callback) -- the plain form everywhere.
+    int64_t cut_agreed[3] = {0, 0, 0};
+    bool cut_agreed_ready = false;
     std::vector<std::unique_ptr<CutLevel>> cutlv;   // [nlevels]
     bool sharers = false;                        // exchange among the sharers of each cut entity (segments) instead of one
                                                  // all-reduce over the global cut buffer; needs a p2p transport (below)
@@ -936,6 +941,35 @@ void exchange_run(hmg_grid *g, const LevelDev &lv, bool async);
 void exchange_finish(hmg_grid *g, const LevelDev &lv, bool async);
 
 
+// The size of the cut as EVERY rank sees it: per kind the number of cut entities of the whole partition.  A global analysis
+// knows it (Partition::nglobal); a halo-only analysis knows the entities this rank shares -- each is counted by the lowest
+// rank among its sharers (the segment's first member) and the counts are summed over the ranks through the scalar_sum
+// callback, once per partition analysis (first apply on the partitioned grid, and again after a domain shrink).  Collective:
+// every rank reaches it at the same point of the same call sequence.
+void agree_on_cut(hmg_grid *g)
+{
+    if (g->cut_agreed_ready) return;
+    const Partition &P = *g->part;
+    hmg_ctx *c = g->ctx;
+    if (P.global_ids) {
+        for (int k = 0; k < 3; ++k) g->cut_agreed[k] = g->cut[k].nglobal;
+    } else if (!g->scalar_sum) {
+        for (int k = 0; k < 3; ++k) g->cut_agreed[k] = -1;        // nothing to agree with: the plain form on every rank
+    } else {
+        double lead[3] = {0.0, 0.0, 0.0};
+        for (const Partition::Segment &S : P.segs)
+            if (!S.members.empty() && S.members.front() == P.rank)
+                for (int k = 0; k < 3; ++k) lead[k] += (double)S.count[k];
+        double *d = c->L.scal + S_HOST;           // (the last slots of the scalar bank are not used by the kernels)
+        HIPCHK(hipMemcpyAsync(d, lead, sizeof(lead), hipMemcpyHostToDevice, c->stream));
+        scalar_sum(g, S_HOST, 3);
+        HIPCHK(hipMemcpyAsync(lead, d, sizeof(lead), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 3; ++k) g->cut_agreed[k] = (int64_t)std::llround(lead[k]);
+    }
+    g->cut_agreed_ready = true;
+}
+
 struct TimedRegion {   // HIP-event bracket of the finest-level operator applies (bench.py roofline)
     hmg_ctx *c;
     bool timed;
@@ -988,8 +1022,13 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     // form after them, and calls on one communicator have to come in one order everywhere.  So it looks at the global size of
     // the cut on this level (identical on all ranks), never at what this rank happens to own; a rank without cut cells walks
     // the overlapped form with empty lists.
-    const bool has_cut = has_exchange(g) && g->part && g->cut[0].nglobal + g->cut[1].nglobal + g->cut[2].nglobal > 0;
-    const int64_t global_cut = has_cut ? g->cut[0].nglobal * lv.nfi + g->cut[1].nglobal * lv.nei + g->cut[2].nglobal : 0;
+    // (round 3 read CutKind::nglobal here, which counts only the cut entities THIS rank has a copy of once the partition is
+    //  analysed on the rank's halo: ranks on either side of the threshold chose different forms -- ADVICE r3.  The counts are
+    //  now summed over the ranks once per partition analysis, every entity counted by the lowest rank that shares it.)
+    if (has_exchange(g) && g->part) agree_on_cut(g);
+    const bool has_cut = has_exchange(g) && g->part && g->cut_agreed[0] >= 0 &&
+                         g->cut_agreed[0] + g->cut_agreed[1] + g->cut_agreed[2] > 0;
+    const int64_t global_cut = has_cut ? g->cut_agreed[0] * lv.nfi + g->cut_agreed[1] * lv.nei + g->cut_agreed[2] : 0;
     const bool overlap = has_cut && (g->sharers ? g->p2p_begin != nullptr : g->ex_begin != nullptr) && g->ex_end && g->overlap &&
                          global_cut >= std::max<int64_t>(1, c->overlap_min_doubles);
     auto launch = [&](const int32_t *list, int64_t n) {
@@ -2987,6 +3026,7 @@ static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const i
         if (seen.emplace(c.gid[i], 1).second) first[i] = 1;
     }
     g->cutlv.clear();                            // buffer layouts are rebuilt at the next exchange
+    g->cut_agreed_ready = false;                 // ... and the ranks agree on the size of the new cut at the next apply
     if (!g->ctx) return;
     c.cell_lid.upload(hc, g->ctx->stream);
     c.first.upload(first, g->ctx->stream);
@@ -3013,6 +3053,7 @@ int hmg_grid_set_exchange(hmg_grid *g, hmg_exchange_fn exchange, hmg_exchange_fn
     need(g != nullptr, "null grid");
     g->exchange = exchange;
     g->scalar_sum = scalar_sum_fn;
+    g->cut_agreed_ready = false;
     g->ex_user = user;
     g->ex_buf = (double *)device_exchange_buf;
     g->ex_cap = exchange_buf_doubles;
@@ -3136,6 +3177,7 @@ int hmg_grid_use_comm(hmg_grid *g)
     g->ex_user = g;
     g->exchange = comm_exchange;             // (the level-1 gather stays an all-reduce of the global nodal vector)
     g->scalar_sum = comm_exchange;           // (the same in-place sum, on the scalar bank)
+    g->cut_agreed_ready = false;
     g->ex_begin = comm_exchange_begin;
     g->ex_end = comm_exchange_end;
     g->p2p = comm_p2p_sync;

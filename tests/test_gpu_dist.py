@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, width, levels, overlap, q, own_stream=False):
+def _worker(rank, world, port, width, levels, overlap, q, own_stream=False, threshold="all"):
     try:
         sys.path.insert(0, ROOT)
         import torch
@@ -56,6 +56,16 @@ def _worker(rank, world, port, width, levels, overlap, q, own_stream=False):
         g = prob.implicit
         prob.exchange.set_overlap(g, overlap)
         ctx.set_option("overlap_min_doubles", 1)              # (small meshes: overlap every level so that the path is exercised)
+        if threshold == "between":
+            # a threshold BETWEEN the ranks' own finest-level cut sizes.  A decision taken from rank-local
+            # numbers would send some ranks down the overlapped form (exchange before the scalar sums) and the others down the
+            # plain one (after them): mismatched collectives.  The library must decide from a number all ranks agree on.
+            mine = torch.tensor([float(g._lib.hmg_grid_cut_buffer_doubles(g.h, levels))], dtype=torch.float64)
+            every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(every, mine)
+            sizes = sorted(int(t.item()) for t in every)
+            assert sizes[0] < sizes[-1], sizes                 # (the partition must be asymmetric for this test to mean anything)
+            ctx.set_option("overlap_min_doubles", (sizes[0] + sizes[-1]) // 2)
         L = levels
         # serial oracle on the global mesh with the same inputs
         gm = O.Mesh(prob.global_base.nodes, prob.global_base.elements - 1)
@@ -109,6 +119,28 @@ def test_multi_rank_vcycle_matches_serial_oracle(world, width, levels, overlap, 
     res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    for rank, msg in sorted(res):
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.parametrize("world,width,levels", [(3, "delaunay3", 3), (3, 3, 4)])
+def test_overlap_decision_is_the_same_on_every_rank(world, width, levels):
+    """Asymmetric partitions (hashed owners; three slabs: the middle rank has twice the cut of the end ranks) with the overlap
+    threshold between the ranks' local cut sizes: two V-cycles against the serial oracle, no deadlock."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, levels, True, q, False, "between")) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=300) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
     for rank, msg in sorted(res):
         assert msg == "ok", f"rank {rank}: {msg}"
 
