@@ -111,22 +111,202 @@ def cpu_time_to_tolerance(hmg, driver, n, refinements, tolerance, max_seconds):
             "cores": int(O.available_cores()), "kind": "port"}
 
 
-def launcher_command(ngpus, argv, port):
-    """The torch.distributed.run command line `python bench.py --gpus N ...` turns itself into (one rank per GPU, RCCL)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+def launcher_command(ngpus, argv):
+    """The torch.distributed.run command line `python bench.py --gpus N ...` turns itself into (one rank per GPU, RCCL).
+    --standalone: the launcher picks its own rendezvous port on the loopback interface (no probe-then-reuse race)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+            f"--nproc-per-node={ngpus}", os.path.abspath(__file__)] + list(argv)
 
 
 def self_launch(ngpus, argv):
-    import socket
     import subprocess
-    with socket.socket() as s:              # a free rendezvous port on the loopback interface
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this platform (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(launcher_command(ngpus, argv, port), env=env)
+    return subprocess.call(launcher_command(ngpus, argv), env=env)
+
+
+# ---- N > 1: every rank the launcher starts is a SUPERVISOR ----------------------------------------------------------------
+# The N > 1 RCCL path (grouped ncclSend / ncclRecv among the sharers of the cut, overlapped on a second stream) has never run
+# on more than one physical GPU, and this bench is the only place it ever will.  So the process torch.distributed.run starts
+# does not touch the GPU: it starts the real rank as a CHILD with a time limit and, should that attempt fail or hang on ANY
+# rank, a fresh child with HMG_EXCHANGE=allreduce HMG_OVERLAP=0 -- the exchange form that ran on hardware in round 2 -- with a
+# fresh rendezvous (a file store per attempt: no key of the dead attempt can collide).  The supervisors of one node agree through
+# marker files in a directory all of them derive alike (the launcher's pid + its rendezvous port): `fail_<k>` ends attempt k
+# everywhere, `ok_<k>_<rank>` from every rank lets rank 0 forward its child's JSON line, to which it adds which attempt produced
+# the number.  Both attempts failing is a non-zero exit and no number.
+ATTEMPTS = (("p2p", {}), ("allreduce", {"HMG_EXCHANGE": "allreduce", "HMG_OVERLAP": "0"}))
+
+
+def supervisor_dir(env):
+    import tempfile
+    tag = f"{os.getppid()}_{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'x')}"
+    return os.path.join(tempfile.gettempdir(), "hmg_bench_" + "".join(ch if ch.isalnum() or ch == "_" else "_" for ch in tag))
+
+
+def supervise_rank(argv, child_cmd=None):
+    """Runs in every process torch.distributed.run starts for `bench.py --gpus N` (before torch or HIP are imported).
+    child_cmd: the command of the real rank (tests substitute a stub); returns the exit code of the supervisor."""
+    import signal
+    import subprocess
+    env0 = dict(os.environ)
+    rank, world = int(env0.get("RANK", "0")), int(env0.get("WORLD_SIZE", "1"))
+    limit = float(env0.get("HMG_BENCH_ATTEMPT_SECONDS", "600"))
+    grace = float(env0.get("HMG_BENCH_BARRIER_SECONDS", "60"))
+    d = supervisor_dir(env0)
+    os.makedirs(d, exist_ok=True)
+    cmd = child_cmd or [sys.executable, os.path.abspath(__file__)] + list(argv)
+    failures = []
+
+    def touch(name):
+        with open(os.path.join(d, name), "w") as f:
+            f.write(str(rank))
+
+    def kill(proc):
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)        # (the child is the leader of its own session: exactly our process group)
+            try:
+                proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait(timeout=30)
+        except (ProcessLookupError, subprocess.TimeoutExpired):
+            pass
+
+    for k, (form, extra) in enumerate(ATTEMPTS, start=1):
+        env = dict(env0)
+        env.update(extra)
+        env.update(HMG_BENCH_SUPERVISED="1", HMG_BENCH_ATTEMPT=str(k), HMG_BENCH_RDZV="file://" + os.path.join(d, f"rdzv_{k}"))
+        fail, out_path = os.path.join(d, f"fail_{k}"), os.path.join(d, f"stdout_{k}_{rank}")
+        t0 = time.time()
+        with open(out_path, "w") as out:
+            proc = subprocess.Popen(cmd, env=env, stdout=out, start_new_session=True)
+        why = None
+        while True:
+            rc = proc.poll()
+            if rc is not None:
+                if rc != 0:
+                    why = f"rank {rank}: child exit code {rc}"
+                break
+            if os.path.exists(fail):
+                time.sleep(2.0)                       # (a peer failed: this child cannot finish -- give it a moment to say why)
+                kill(proc)
+                why = f"rank {rank}: stopped, a peer's attempt failed"
+                break
+            if time.time() - t0 > limit:
+                kill(proc)
+                why = f"rank {rank}: no result within {limit:.0f} s"
+                break
+            time.sleep(0.2)
+        if why is None:
+            touch(f"ok_{k}_{rank}")
+            t1 = time.time()                          # all ranks done?  (a rank may still fail in its teardown)
+            while why is None and not all(os.path.exists(os.path.join(d, f"ok_{k}_{r}")) for r in range(world)):
+                if os.path.exists(fail):
+                    why = f"rank {rank}: a peer's attempt failed after this rank had finished"
+                elif time.time() - t1 > grace + max(0.0, limit - (t1 - t0)):
+                    why = f"rank {rank}: peers did not finish"
+                time.sleep(0.1)
+        if why is None:
+            if rank == 0:
+                line = None
+                for l in open(out_path).read().splitlines():
+                    if l.startswith("{"):
+                        line = l
+                if line is None:
+                    print("bench supervisor: rank 0 finished without a JSON line", file=sys.stderr, flush=True)
+                    return 1
+                rec = json.loads(line)
+                rec["launcher"] = {"supervised": True, "attempt": k, "exchange_form": form, "failed_attempts": failures}
+                print(json.dumps(rec), flush=True)
+                time.sleep(0.5)
+                import shutil
+                shutil.rmtree(d, ignore_errors=True)
+            return 0
+        touch(f"fail_{k}")
+        failures.append({"attempt": k, "exchange_form": form, "why": why})
+        print(f"bench supervisor: attempt {k} ({form}) failed -- {why}", file=sys.stderr, flush=True)
+    return 1
+
+
+def preflight(ctx, hmg, hdist, dist, world, rank, width=None, levels=5):
+    """Before anything is timed on N > 1 ranks: does the partitioned V-cycle compute what the unpartitioned one does?
+    A small brick (width^3 unit cubes per rank, level 5 on top) is solved twice by every rank -- partitioned over the N ranks
+    with the exchange form of this run, and whole, unpartitioned, on the rank's own GPU -- from the same x0 and b (host twin of
+    the device generator), two V-cycles each; the rank compares its columns.  Then the same partitioned V-cycles with the OTHER
+    exchange form (all-reduce over the global cut buffer <-> messages among the sharers): both forms add the ranks' partial sums
+    in ascending rank order, so x and r are expected to agree bit for bit.  Returns the record for the JSON line; `ok` = every
+    rank within 1e-9 (x) / 1e-8 (r)."""
+    import numpy as np
+    import torch
+    width = width or int(os.environ.get("HMG_PREFLIGHT_WIDTH", "8"))
+    form = "allreduce" if os.environ.get("HMG_EXCHANGE", "") == "allreduce" else "p2p"
+
+    def solve(grid, op, base_level, x0, b0, cols):
+        st = [hmg.LevelState(grid, i + 1) for i in range(levels)]
+        st[-1].x.from_host(x0[:, cols])
+        st[-1].b.from_host(b0[:, cols])
+        hmg.broadcast_interfaces(st[-1].x, grid, levels)
+        hmg.apply_constraint(st[-1].x, levels, grid)
+        for _ in range(2):
+            hmg.vcycle(grid, base_level, [op] * levels, st, levels, 3)
+        out = st[-1].x.to_host(), st[-1].r.to_host()
+        for q in st:
+            q.close()
+        return out
+
+    def partitioned(which):
+        keep = {k: os.environ.get(k) for k in ("HMG_EXCHANGE",)}
+        try:
+            if which == "allreduce":
+                os.environ["HMG_EXCHANGE"] = "allreduce"
+            else:
+                os.environ.pop("HMG_EXCHANGE", None)
+            prob = hdist.partitioned_checkerboard(ctx, width, levels, world, rank, seed=7)
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        if os.environ.get("HMG_OVERLAP") == "0":
+            prob.exchange.set_overlap(prob.implicit, False)
+        ctx.set_option("overlap_min_doubles", 1)          # (small brick: force the overlapped form where overlap is on)
+        return prob
+
+    try:
+        prob = partitioned(form)
+        g = prob.implicit
+        ne = prob.global_base.elements.shape[0]
+        nf = g.nf(levels)
+        x0 = hmg.host_random((nf, ne), 11)
+        b0 = hmg.host_random((nf, ne), 12) - 0.5
+        xp, rp = solve(g, prob.op, prob.base_level(), x0, b0, g.local_cells)
+        whole = hmg.ImplicitFineGrid(ctx, prob.global_base, levels)
+        op_w = hmg.L2PlusDivAGrad(whole, 1.0, prob.cond)
+        xw, rw = solve(whole, op_w, hmg.BaseLevel(whole), x0, b0, slice(None))
+        ex = float(np.abs(xp - xw[:, g.local_cells]).max() / max(np.abs(xw).max(), 1e-300))
+        er = float(np.abs(rp - rw[:, g.local_cells]).max() / max(np.abs(rw).max(), 1e-300))
+        other = "p2p" if form == "allreduce" else "allreduce"
+        same = None
+        try:
+            prob2 = partitioned(other)
+            xo, ro = solve(prob2.implicit, prob2.op, prob2.base_level(), x0, b0, prob2.implicit.local_cells)
+            same = bool(np.array_equal(xo, xp) and np.array_equal(ro, rp))
+        except Exception as e:                             # (the other form is a cross-check, not a requirement)
+            same = f"other form failed: {e}"
+        worst = torch.tensor([ex, er, 0.0 if same is True else 1.0], dtype=torch.float64)
+        if dist is not None and world > 1:
+            dev = worst.cuda() if dist.get_backend() == "nccl" else worst
+            dist.all_reduce(dev, op=dist.ReduceOp.MAX)
+            worst = dev.cpu()
+        ex, er = float(worst[0]), float(worst[1])
+        return {"ranks": world, "brick": f"{prob.global_shape} unit cubes ({width}^3 per rank), levels={levels}, 2 V-cycles",
+                "exchange": form, "rel_err_x": ex, "rel_err_r": er, "tolerance": {"x": 1e-9, "r": 1e-8},
+                "other_form_bit_identical": (same if not isinstance(same, bool) else bool(float(worst[2]) == 0.0)),
+                "ok": bool(ex <= 1e-9 and er <= 1e-8)}
+    finally:
+        ctx.set_option("overlap_min_doubles", 524288)
 
 
 def main():
@@ -144,6 +324,10 @@ def main():
     ap.add_argument("--cpu-driver-seconds", type=float, default=75.0,
                     help="time limit of the CPU oracle's run of the driver on BASELINE config 2")
     ap.add_argument("--apply-threads", type=int, default=None)
+    ap.add_argument("--no-level-report", dest="level_report", action="store_false",
+                    help="skip the per-level breakdown (roofline.levels), measured after the timed region")
+    ap.add_argument("--untuned-burst", type=int, default=3,
+                    help="V-cycles timed (outside the timed region) before the placement tuner runs: config.placement.ms_per_step_untuned")
     ap.add_argument("--tune-placement", type=int, default=8,
                     help="candidates of hmg_level_tune_placement for the finest level's five vectors (setup, untimed); 0 = off")
     args = ap.parse_args()
@@ -153,6 +337,10 @@ def main():
         # torch.distributed.run, started before this process has imported torch or touched HIP (no exec of a process
         # that holds the GPU); their stdout (rank 0's JSON line) and stderr pass straight through.
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("HMG_BENCH_SUPERVISED") != "1" and \
+            os.environ.get("HMG_BENCH_NO_SUPERVISOR") != "1":
+        # a rank started by a launcher (the driver's torch.distributed.run, or ours): supervise the real rank, see above
+        raise SystemExit(supervise_rank(sys.argv[1:]))
 
     # Only the JSON line goes to this process's stdout: libraries underneath write there too (RCCL prints a version
     # banner when a communicator is created, gloo its rank-connection lines), so file descriptor 1 points at stderr until
@@ -193,10 +381,13 @@ def main():
                 port = s.getsockname()[1]
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         backend = os.environ.get("HMG_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        # (a supervised attempt brings its own rendezvous: a fresh file store per attempt, see supervise_rank)
+        rdzv = os.environ.get("HMG_BENCH_RDZV")
+        kw = {"init_method": rdzv, "rank": rank, "world_size": world} if rdzv else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = hmg.Context(local_rank, stream=stream)
@@ -206,6 +397,19 @@ def main():
 
     L = args.levels
     w = args.width
+    pre = None
+    if (world > 1 or os.environ.get("HMG_BENCH_PREFLIGHT") == "1") and os.environ.get("HMG_BENCH_PREFLIGHT") != "0" and \
+            rehearse_world is None:
+        from homogenization_jl_amd import dist as hdist
+        pre = preflight(ctx, hmg, hdist, dist, world, rank)
+        if not pre["ok"]:
+            # wrong numbers from this exchange form: no timing is reported for it.  Under the supervisor the non-zero exit starts
+            # the attempt with the other form on every rank.
+            if rank == 0:
+                print("bench: PREFLIGHT FAILED " + json.dumps(pre), file=sys.stderr, flush=True)
+            if dist is not None:
+                dist.destroy_process_group()
+            raise SystemExit(3)
     t_setup0 = time.perf_counter()
     if world > 1 or force_part:
         from homogenization_jl_amd import dist as hdist
@@ -230,6 +434,22 @@ def main():
     states = [hmg.LevelState(implicit, i + 1) for i in range(L)]
     top = states[-1]
     placement = {"tuned": False}
+    base_level = prob.base_level() if (world > 1 or force_part) else hmg.BaseLevel(implicit)
+    if args.tune_placement > 0 and args.untuned_burst > 0:
+        # the V-cycle as the allocator happened to place the level vectors (what the driver's checkerboard_homogenization runs):
+        # a short burst before the tuner moves anything
+        top.x.rand(1234, cell_offset=rank * ne_local)
+        hmg.broadcast_interfaces(top.x, implicit, L)
+        hmg.apply_constraint(top.x, L, implicit)
+        hmg.rhs_axi_grad_v(top.b, implicit, driver.random_unit_vec(3))
+        hmg.vcycle(implicit, base_level, [op] * L, states, L, args.smoothing_steps)
+        ctx.sync()
+        t_u = time.perf_counter()
+        for _ in range(args.untuned_burst):
+            hmg.vcycle(implicit, base_level, [op] * L, states, L, args.smoothing_steps)
+        ctx.sync()
+        placement["ms_per_step_untuned"] = 1e3 * (time.perf_counter() - t_u) / args.untuned_burst
+        placement["untuned_burst_steps"] = args.untuned_burst
     if args.tune_placement > 0:
         # setup, like an FFT plan: which of the finest level's memory blocks (+ 2 spare ones, freed again) plays x, b, r, p,
         # Ap is chosen by timing that level's share of a V-cycle per candidate (include/hmg.h, hmg_level_tune_placement)
@@ -237,14 +457,13 @@ def main():
         t_tune0 = time.perf_counter()
         before, after = hmg.tune_placement(implicit, [op] * L, states, L, args.smoothing_steps, trials=args.tune_placement, extra=2)
         ctx.sync()
-        placement = {"tuned": True, "candidates": args.tune_placement, "spare_blocks": 2,
+        placement = {**placement, "tuned": True, "candidates": args.tune_placement, "spare_blocks": 2,
                      "finest_level_share_of_a_vcycle_ms_as_allocated": before, "finest_level_share_of_a_vcycle_ms_chosen": after,
                      "seconds": time.perf_counter() - t_tune0}
     top.x.rand(1234, cell_offset=rank * ne_local)
     hmg.broadcast_interfaces(top.x, implicit, L)
     hmg.apply_constraint(top.x, L, implicit)
     hmg.rhs_axi_grad_v(top.b, implicit, driver.random_unit_vec(3))
-    base_level = prob.base_level() if (world > 1 or force_part) else hmg.BaseLevel(implicit)
     ops = [op] * L
     ctx.sync()
     setup_seconds = time.perf_counter() - t_setup0     # mesh synthesis, tables, partition, level vectors, x0, b, level-1 matrix
@@ -258,12 +477,14 @@ def main():
     for _ in range(args.warmup):
         hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
     barrier()
+    comm0 = prob.exchange.stats() if (world > 1 or force_part) else (0, 0)
     ctx.set_option("time_apply", L)          # HIP events around the finest-level operator applies
     t0 = time.perf_counter()
     for _ in range(args.steps):
         hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
     barrier()
     dt = time.perf_counter() - t0
+    comm1 = prob.exchange.stats() if (world > 1 or force_part) else (0, 0)
     if (world > 1 or force_part) and os.environ.get("HMG_EXCHANGE_STATS") == "1":
         ex = prob.exchange
         ncalls, ndoubles = ex.stats()
@@ -273,10 +494,42 @@ def main():
     ctx.set_option("time_apply", 0)
     rnorm = hmg.norm_unique(top.r)            # first copies only; summed over ranks by the library
 
+    # Outside the timed region: every level's operator applies between HIP events (two more V-cycles with the timer on for all
+    # levels -- inside the timed region only the finest level is timed, an event pair per launch of the launch-bound small levels
+    # would move the headline), and each level's whole share of a V-cycle (vector kernels, interface sums, transfers included)
+    # from V-cycles started one level lower each time.
+    level_rows = []
+    if args.level_report:
+        ctx.set_option("time_apply", 1)
+        nrep = 2
+        for _ in range(nrep):
+            hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
+        ctx.sync()
+        per_level = {k: ctx.apply_timing_level(k) for k in range(1, L + 1)}
+        ctx.set_option("time_apply", 0)
+        from_level = {L: 1e3 * dt / args.steps}
+        for k in range(L - 1, 0, -1):
+            hmg.vcycle(implicit, base_level, ops, states, k, 2)
+            ctx.sync()
+            t_k = time.perf_counter()
+            for _ in range(3):
+                hmg.vcycle(implicit, base_level, ops, states, k, 2)
+            ctx.sync()
+            from_level[k] = 1e3 * (time.perf_counter() - t_k) / 3
+        for k in range(L, 0, -1):
+            n_k, ms_k, by_k = per_level[k]
+            level_rows.append({"level": k, "nf": implicit.nf(k),
+                               "apply_launches_per_vcycle": n_k / nrep, "apply_ms_per_vcycle": ms_k / nrep,
+                               "apply_algorithmic_GB_per_vcycle": by_k / nrep / 1e9,
+                               "apply_TBps": (by_k / 1e12) / (ms_k * 1e-3) if ms_k > 0 else None,
+                               "level_share_ms": from_level[k] - from_level.get(k - 1, 0.0)})
+
+    dt_rank_min = dt_rank_max = dt
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, -dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt_rank_max, dt_rank_min = float(t[0].item()), -float(t[1].item())
+        dt = dt_rank_max
         tot = torch.tensor([float(ne_local)], dtype=torch.float64, device="cuda")
         dist.all_reduce(tot)
         ne_total = int(tot.item())
@@ -290,14 +543,28 @@ def main():
         achieved = (nbytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled
         # as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); cannot be collected inside this process.
+        # ... and only next to the build they were collected on: the record carries the sha256 of the library file and of its
+        # sources (homogenization_jl_amd._lib.fingerprint, written by tools/collect_profiles.sh on the GPU box)
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "apply_traffic.json")
-        if os.path.exists(pmc) and world == 1 and w == 32 and L == 6:
+        fp = hmg._lib.fingerprint()
+        if not (world == 1 and w == 32 and L == 6):
+            traffic_src = "not collected for this workload (profiles/apply_traffic.json is BASELINE config 3 on one GPU)"
+        elif not os.path.exists(pmc):
+            traffic_src = "profiles/apply_traffic.json missing"
+        else:
             try:
                 rec = json.load(open(pmc))
-                traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
-            except Exception:
-                traffic = None
+                if rec.get("lib_sha256") and rec.get("lib_sha256") == fp["lib_sha256"]:
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source") + " [same library file as this run]"
+                elif rec.get("src_sha256") and rec.get("src_sha256") == fp["src_sha256"]:
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source") + " [same kernel sources as this run]"
+                else:
+                    traffic_src = ("stale: profiles/apply_traffic.json was collected on another build (its lib/src sha256 " +
+                                   f"{str(rec.get('lib_sha256'))[:12]}/{str(rec.get('src_sha256'))[:12]}, this run " +
+                                   f"{str(fp['lib_sha256'])[:12]}/{str(fp['src_sha256'])[:12]})")
+            except Exception as e:
+                traffic_src = f"unreadable: {e}"
         out = {
             "metric": "fine-DOF updates/sec per V-cycle (3D Tet64)",
             "value": value,
@@ -326,8 +593,26 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": int(launches), "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": nbytes / max(launches, 1)},
+                         "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
+                         "levels": level_rows,
+                         "levels_note": "outside the timed region: operator applies of every level between HIP events over 2 more "
+                                        "V-cycles (level 5: one wave per cell, hmg::k_apply_wave), and each level's whole share of "
+                                        "a V-cycle from V-cycles started one level lower each time"},
+            "build": fp,
         }
+        out["ms_per_step_ranks"] = {"min": 1e3 * dt_rank_min / args.steps, "max": ms_step}
+        if world > 1 or force_part:
+            ex = prob.exchange
+            out["comm"] = {"backend": ex.backend,
+                           "nranks_rccl": ctx.counter("comm_nranks") if ex.backend == "rccl" else None,
+                           "nranks_torch": world,
+                           "exchange": "p2p" if ex.sharers else "allreduce",
+                           "overlap": os.environ.get("HMG_OVERLAP") != "0",
+                           "collectives_per_vcycle_rank0": (comm1[0] - comm0[0]) / args.steps,
+                           "doubles_per_rank_per_vcycle": (comm1[1] - comm0[1]) / args.steps,
+                           "attempt": int(os.environ.get("HMG_BENCH_ATTEMPT", "1"))}
+        if pre is not None:
+            out["preflight"] = pre
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_width, L, args.smoothing_steps)
         if world == 1 and not args.no_time_to_tolerance and (w, L) == (32, 6):

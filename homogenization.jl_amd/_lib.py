@@ -33,6 +33,8 @@ SIGNATURES = {
     "hmg_ctx_set_option_f64": (c_int, [vp, ctypes.c_char_p, c_f64]),
     "hmg_ctx_scalar_bank": (vp, [vp]),
     "hmg_ctx_apply_timing": (c_int, [vp, p_i64, p_f64, p_f64]),
+    "hmg_ctx_counter": (c_i64, [vp, ctypes.c_char_p]),
+    "hmg_ctx_apply_timing_level": (c_int, [vp, c_int, p_i64, p_f64, p_f64]),
     "hmg_rhs_axi_grad": (c_int, [vp, p_f64, vp]),
     "hmg_next_rhs": (c_int, [vp, vp, vp]),
     "hmg_local_rhs": (c_int, [vp, vp]),
@@ -134,14 +136,44 @@ def load():
             except Exception:
                 pass
         lib = ctypes.CDLL(LIB_PATH)
+        # A/B run against an OLDER build (HMG_LIB_PATH=... HMG_LIB_AB=1): entry points added since are absent there; calling one
+        # raises a clear error.  Without HMG_LIB_AB a missing symbol fails here, at load time (a stale build must not surface
+        # as an AttributeError in the middle of a collective).
+        ab = bool(os.environ.get("HMG_LIB_PATH")) and os.environ.get("HMG_LIB_AB") == "1"
         for name, (res, args) in SIGNATURES.items():
-            if os.environ.get("HMG_LIB_PATH") and not hasattr(lib, name):
-                continue                     # A/B run against an older build: entry points added since are absent there
-            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            if ab and not hasattr(lib, name):
+                def _absent(*_a, _n=name):
+                    raise HmgError(f"{_n} is not exported by {LIB_PATH} (older build loaded through HMG_LIB_PATH / HMG_LIB_AB)")
+                setattr(lib, name, _absent)
+                continue
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise ImportError(f"{LIB_PATH} does not export {name}, which include/hmg.h declares: stale or mismatched "
+                                  "build (rebuild, or set HMG_LIB_AB=1 for an A/B run against an older build)") from e
             fn.restype = res
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def fingerprint():
+    """What build is this?  sha256 of the library file that gets loaded and of the sources it is made from (csrc/ + include/hmg.h).
+    bench.py reports a profile-derived number only next to the build it was measured on (profiles/apply_traffic.json)."""
+    import glob
+    import hashlib
+
+    def sha(paths):
+        h = hashlib.sha256()
+        for q in paths:
+            h.update(os.path.basename(q).encode())
+            with open(q, "rb") as f:
+                h.update(f.read())
+        return h.hexdigest()
+    src = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.hpp")) +
+                 glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + glob.glob(os.path.join(_HERE, "csrc", "Makefile")) +
+                 [os.path.join(os.path.dirname(_HERE), "include", "hmg.h")])
+    return {"lib_sha256": sha([LIB_PATH]) if os.path.exists(LIB_PATH) else None, "src_sha256": sha([q for q in src if os.path.exists(q)])}
 
 
 def check(rc):

@@ -107,6 +107,19 @@ class Context:
         else:
             L.check(self._lib.hmg_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def apply_timing_level(self, level: int):
+        """(launches, total_ms, algorithmic_bytes) of the timed operator applies of one level (option "time_apply" = 1 times
+        every level)."""
+        n = ctypes.c_int64()
+        ms = ctypes.c_double()
+        by = ctypes.c_double()
+        L.check(self._lib.hmg_ctx_apply_timing_level(self.h, int(level), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)))
+        return n.value, ms.value, by.value
+
+    def counter(self, name: str) -> int:
+        """Diagnostic counters of the library ("wave_launches": launches of the one-wave-per-cell level-5 apply)."""
+        return int(self._lib.hmg_ctx_counter(self.h, name.encode()))
+
     def apply_timing(self):
         """(launches, total_ms, algorithmic_bytes) of the operator applies timed since option
         "time_apply" was last set."""

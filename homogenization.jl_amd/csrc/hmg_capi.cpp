@@ -94,6 +94,9 @@ struct LevelBufs {
     DevBuf<uint16_t> rs_lp;
     DevBuf<uint16_t> blk_slot;
     int nblk = 0, blk_R = 0;
+    // one-wave-per-cell apply of level 5 (k_apply_wave): per-lane tables + the class-weight cache of the current operator
+    DevBuf<uint32_t> wave_tab, wave_lpos, wave_par, wave_cl, wave_rs;
+    DevBuf<double> wcache;
     DevBuf<double> ctab;
     DevBuf<int32_t> hier2slot, par_a, par_b, rptr, ridx;
     DevBuf<double> dphi;
@@ -129,6 +132,8 @@ struct ApplyTimer {
     bool on = false;
     int min_level = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::vector<int> ev_level;          // per used event pair: the level of the launch and its algorithmic bytes
+    std::vector<double> ev_bytes;
     size_t used = 0;
     double bytes = 0.0;
     int64_t launches = 0;
@@ -147,6 +152,7 @@ struct hmg_ctx {
     bool lazy_dead = true;      // V-cycle: the pre-smoother's dead last step writes nothing (see smooth())
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
+    bool lazy_post = true;      // ... and below the finest level its dead last step writes nothing: both x-updates in one pass
     bool zero_entry = true;        // V-cycle: a coarse level's zero initial guess is never materialised (see vcycle_down())
     bool fold_restrict = true;     // V-cycle: the restriction rides in the epilogue of the local residual, which is then not stored
     bool prolong_in_image = true;  // folded prolongation, level 6: the coarse column is staged at the even nodes of the lattice image
@@ -166,6 +172,7 @@ struct hmg_ctx {
     hipStream_t comm_stream = nullptr;       // the overlapped cut exchange runs here
     hipEvent_t ev_packed = nullptr, ev_summed = nullptr;
     int64_t comm_calls = 0, comm_doubles = 0;
+    int64_t wave_launches = 0;               // launches of the one-wave-per-cell apply (hmg_ctx_counter)
     // Level-vector memory handed back by hmg_vec_destroy, kept for the next hmg_vec_create of the same size: on this
     // platform hipMalloc of memory the process has freed before costs ~35 ms per GB (tools/dev/alloc_probe.hip: 6 x 10 GB
     // 0.001 s fresh, 2.05 s after a hipFree), i.e. 1.9 s of the 71 GB a second driver call allocates.
@@ -276,6 +283,12 @@ struct hmg_grid {
     bool fuse_cg = true;
     DevBuf<double> d_coef;
     std::vector<double> sigma, coef;
+    // class-weight cache (k_apply_wave): cells with bitwise equal coefficient rows share a class
+    DevBuf<int32_t> d_cell_class;
+    DevBuf<double> d_coef_rep;
+    int nclasses = 0;
+    double wc_lambda = 0.0;
+    bool wc_ready = false;
     double lambda = 0.0;
     bool has_op = false;
     // coarse system
@@ -495,6 +508,8 @@ static void upload_levels(hmg_grid *g)
         const LevelTables &T = g->lt[l];
         g->lb.emplace_back(new LevelBufs);
         LevelBufs &B = *g->lb.back();
+        std::vector<uint32_t> B_blk_word_host;     // host copies for the tables of k_apply_wave (below)
+        std::vector<uint16_t> B_blk_slot_host, wave_cl_host;
         if (g->ctx) {
             B.meta.upload(T.meta, s);
             {
@@ -588,6 +603,8 @@ static void upload_levels(hmg_grid *g)
                 if (!ok) throw std::runtime_error("blocked apply: the class table does not match the kernel's face / edge tap masks");
                 B.nblk = (int)bw.size();
                 B.blk_R = R;
+                B_blk_word_host = bw;
+                B_blk_slot_host = bs;
                 bw.resize(bw.size() + TABLE_PAD, 0u);
                 bs.resize(bs.size() + TABLE_PAD, (uint16_t)0);
                 B.blk_word.upload(bw, s);
@@ -761,6 +778,7 @@ static void upload_levels(hmg_grid *g)
                 }
                 B.clpos.upload(cl, s);
                 B.par64.upload(p64, s);
+                wave_cl_host = cl;
                 // restriction in the epilogue of the local residual (k_apply<.., RS>): addressing word of every coarse slot's
                 // fine node and the weights 1 / 0.5 on the taps that exist (nonzero mass entry of the class table) -- the
                 // weights of the stand-alone restriction (rtab above / launch_restrict_slab)
@@ -788,6 +806,82 @@ static void upload_levels(hmg_grid *g)
                     std::vector<uint16_t> lp(T.ridx.size());
                     for (size_t e = 0; e < lp.size(); ++e) lp[e] = (uint16_t)(T.meta[(size_t)T.ridx[e]] & 0xffffu);
                     B.rs_lp.upload(lp, s);
+                }
+            }
+            if (T.dim == 3 && T.m == 16 && T.nf == 969 && B.nblk == 152 && B.blk_R == 4 && T.lds_g0 == 0 && T.nfi == 105 && T.nei == 15 &&
+                T.ncorner == 4 && T.nedge == 6 && T.nface == 4 && T.off_edge == 4 && T.off_face == 94) {
+                // Tables of k_apply_wave (hmg_apply_wave.hip): what lane l of the one wave that owns a cell needs, row by row.
+                //   wave_tab rows 0..7   faces: run r = 2 f + h covers nodes h * 64 + l of face f
+                //            rows 8..9   corners and edges: slot r * 64 + l (< 94)
+                //            rows 10..12 interior blocks u = r * 64 + l (< 152): the block word of the blocked tables
+                //            row 13      storage slot of block l | of block 64 + l << 16
+                //            row 14      storage slot of block 128 + l | class of slot l << 16 | class of slot 64 + l << 24
+                //   surface words: L | len << 10 | A << 15 | B << 23 | valid << 31 (rows have len = m+1-j-k nodes, A / B = offsets
+                //   to the same (i,j) in the plane above / below, as decode32 derives them)
+                const int m = T.m, WVZ = 168, WDUMMY = 167;
+                auto surf_word = [&](int t, bool valid) -> uint32_t {
+                    const uint32_t L = (uint32_t)(T.meta[(size_t)t] & 0xffffu);
+                    const int j = T.slot_ijk[3 * t + 1], k = T.slot_ijk[3 * t + 2];
+                    const int len = m + 1 - j - k, n = m - k, Tk = (n + 1) * (n + 2) / 2;
+                    const int A = Tk - j, Bo = Tk + n + 2 - j;
+                    if (L > 1023u || len < 0 || len > 31 || A < 0 || A > 255 || Bo < 0 || Bo > 255)
+                        throw std::runtime_error("wave tables: addressing word out of range");
+                    return L | ((uint32_t)len << 10) | ((uint32_t)A << 15) | ((uint32_t)Bo << 23) | (valid ? 1u << 31 : 0u);
+                };
+                std::vector<uint32_t> wt((size_t)WAVE_TAB_ROWS * 64, 0u), wl(8 * 64, 0u);
+                std::vector<uint32_t> bwv(B_blk_word_host.begin(), B_blk_word_host.begin() + B.nblk);
+                for (int l = 0; l < 64; ++l) {
+                    for (int r = 0; r < 8; ++r) {
+                        const int f = r >> 1, ti = (r & 1) * 64 + l;
+                        const bool valid = ti < T.nfi;
+                        wt[(size_t)r * 64 + l] = surf_word(T.off_face + f * T.nfi + (valid ? ti : 0), valid);
+                    }
+                    uint32_t cls[2];
+                    for (int r = 0; r < 2; ++r) {
+                        const int t = r * 64 + l;
+                        const bool valid = t < T.off_face;
+                        wt[(size_t)(8 + r) * 64 + l] = surf_word(valid ? t : 0, valid);
+                        cls[r] = T.slot_cls[(size_t)(valid ? t : T.off_edge)];
+                        if (cls[r] < 5 || cls[r] > 14) throw std::runtime_error("wave tables: edge / corner class out of range");
+                    }
+                    uint32_t bsl[3];
+                    for (int r = 0; r < 3; ++r) {
+                        const int u = r * 64 + l;
+                        const bool valid = u < B.nblk;
+                        // (no block: block 0's addresses with no valid node -- nothing is stored)
+                        wt[(size_t)(10 + r) * 64 + l] = valid ? bwv[(size_t)u] : (bwv[0] & 0x0fffffffu);
+                        bsl[r] = valid ? B_blk_slot_host[(size_t)u] : B_blk_slot_host[0];
+                    }
+                    wt[(size_t)13 * 64 + l] = bsl[0] | (bsl[1] << 16);
+                    wt[(size_t)14 * 64 + l] = bsl[2] | (cls[0] << 16) | (cls[1] << 24);
+                    for (int i = 0; i < 8; ++i) {
+                        uint32_t off[2];
+                        for (int h = 0; h < 2; ++h) {
+                            const int t = l + 64 * (2 * i + h);
+                            off[h] = 8u * (uint32_t)(t < T.nf ? WVZ + (int)(T.meta[(size_t)t] & 0xffffu) : WDUMMY);
+                        }
+                        wl[(size_t)i * 64 + l] = off[0] | (off[1] << 16);
+                    }
+                }
+                B.wave_tab.upload(wt, s);
+                B.wave_lpos.upload(wl, s);
+                if (l > 0 && !wave_cl_host.empty() && g->lt[l - 1].nf == 165) {
+                    const LevelTables &C = g->lt[l - 1];
+                    std::vector<uint32_t> wp(16 * 64, 0u), wc(3 * 64, 8u * (uint32_t)WDUMMY), wr((size_t)192 * 8, 0u);
+                    for (int t = 0; t < T.nf; ++t)
+                        wp[(size_t)(t / 64) * 64 + t % 64] = (uint32_t)wave_cl_host[(size_t)T.par_a[t]] | ((uint32_t)wave_cl_host[(size_t)T.par_b[t]] << 16);
+                    for (int c = 0; c < C.nf; ++c) wc[(size_t)(c / 64) * 64 + c % 64] = 8u * (uint32_t)(WVZ + wave_cl_host[(size_t)c]);
+                    for (int c = 0; c < C.nf; ++c) {
+                        const int b = T.rptr[c], n = T.rptr[c + 1] - b;
+                        if (n < 1 || n > 15) throw std::runtime_error("wave tables: restriction row longer than 15");
+                        uint16_t e[16] = {0};
+                        for (int q = 0; q < n; ++q) e[q] = (uint16_t)(T.meta[(size_t)T.ridx[b + q]] & 0xffffu);
+                        e[15] = (uint16_t)n;
+                        for (int q = 0; q < 8; ++q) wr[(size_t)c * 8 + q] = (uint32_t)e[2 * q] | ((uint32_t)e[2 * q + 1] << 16);
+                    }
+                    B.wave_par.upload(wp, s);
+                    B.wave_cl.upload(wc, s);
+                    B.wave_rs.upload(wr, s);
                 }
             }
             B.rptr.upload(T.rptr, s);
@@ -839,9 +933,86 @@ static void upload_levels(hmg_grid *g)
         D.rptr = B.rptr.p;
         D.ridx = B.ridx.p;
         D.dphi = B.dphi.p;
+        D.wave_tab = B.wave_tab.p;
+        D.wave_lpos = B.wave_lpos.p;
+        D.wave_par = B.wave_par.p;
+        D.wave_cl = B.wave_cl.p;
+        D.wave_rs = B.wave_rs.p;
+        D.wcache = nullptr;                      // (set with the operator: build_weight_cache)
     }
 }
 namespace {
+
+
+// Class-weight cache of the one-wave apply (hmg_apply_wave.hip).  The per-cell weights of the lattice stencil are linear in
+// the cell's coefficient row (|J| P_kl, |J|), and on the meshes this library is built for most rows repeat: a checkerboard
+// has at most 8 sigma triples x 6 tetrahedron orientations = 48 distinct ones.  Cells are classed by the BITS of their row;
+// per class, sign of alpha and level the 15 x 15 weights are formed once on the device (launch_weight_cache), by the same
+// products in the same order as the kernels form them per cell.  More than WC_MAX_CLASSES distinct rows (perturbed or
+// unstructured meshes): no cache, the level keeps the 256-thread kernel.
+constexpr int WC_MAX_CLASSES = 1024;
+
+void build_cell_classes(hmg_grid *g)
+{
+    g->nclasses = 0;
+    g->wc_ready = false;
+    g->md.cell_class = nullptr;
+    g->md.nclasses = 0;
+    for (auto &d : g->ld) d.wcache = nullptr;
+    bool any = false;
+    for (const auto &d : g->ld) any = any || d.wave_tab != nullptr;
+    if (!any || g->dim != 3) return;
+    const int64_t n = g->cur().ncells;
+    struct Key {
+        uint64_t b[8];
+        bool operator==(const Key &o) const { return std::memcmp(b, o.b, sizeof(b)) == 0; }
+    };
+    struct Hash {
+        size_t operator()(const Key &k) const
+        {
+            uint64_t h = 1469598103934665603ull;
+            for (int q = 0; q < 8; ++q) h = (h ^ k.b[q]) * 1099511628211ull;
+            return (size_t)h;
+        }
+    };
+    std::unordered_map<Key, int32_t, Hash> ids;
+    std::vector<int32_t> cls((size_t)n);
+    std::vector<double> rep;
+    for (int64_t c = 0; c < n; ++c) {
+        Key k;
+        std::memcpy(k.b, g->coef.data() + (size_t)c * 8, sizeof(k.b));
+        auto it = ids.find(k);
+        if (it == ids.end()) {
+            if ((int)ids.size() >= WC_MAX_CLASSES) return;           // too many distinct rows: no cache
+            it = ids.emplace(k, (int32_t)ids.size()).first;
+            rep.insert(rep.end(), g->coef.begin() + (size_t)c * 8, g->coef.begin() + (size_t)c * 8 + 8);
+        }
+        cls[(size_t)c] = it->second;
+    }
+    g->nclasses = (int)ids.size();
+    g->d_cell_class.upload(cls, g->ctx->stream);
+    g->d_coef_rep.upload(rep, g->ctx->stream);
+    g->md.cell_class = g->d_cell_class.p;
+    g->md.nclasses = g->nclasses;
+}
+
+// (re)forms the cached weights when the operator or lambda has changed since they were formed; called in front of every
+// apply (a host comparison when nothing has changed)
+void ensure_weight_cache(hmg_grid *g)
+{
+    if (!g->md.cell_class || (g->wc_ready && g->wc_lambda == g->lambda)) return;
+    for (int l = 0; l < g->nlevels; ++l) {
+        LevelDev &D = g->ld[l];
+        if (!D.wave_tab) continue;
+        LevelBufs &B = *g->lb[l];
+        B.wcache.alloc((size_t)g->nclasses * 2 * WAVE_WSTRIDE);
+        launch_weight_cache(g->ctx->L, D, g->d_coef_rep.p, g->nclasses, g->lambda, B.wcache.p);
+        D.wcache = B.wcache.p;
+    }
+    g->wc_lambda = g->lambda;
+    g->md.wc_lambda = g->lambda;
+    g->wc_ready = true;
+}
 
 void upload_operator(hmg_grid *g)
 {
@@ -858,6 +1029,7 @@ void upload_operator(hmg_grid *g)
     if (!g->ctx) return;
     g->d_coef.upload(g->coef, g->ctx->stream);
     g->md.coef = g->d_coef.p;
+    build_cell_classes(g);
 }
 
 void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);   // defined below
@@ -890,12 +1062,16 @@ void apply(hmg_grid *g, const LevelDev &lv, double alpha, const double *x, const
         HIPCHK(hipEventRecord(t.pool[t.used].first, c->stream));
     }
     set_slab(g, lv);
+    ensure_weight_cache(g);
     launch_apply(c->L, lv, g->md, alpha, g->lambda, x, src, out, mask);
     if (timed) {
         HIPCHK(hipEventRecord(t.pool[t.used].second, c->stream));
         t.used += 1;
         t.launches += 1;
-        t.bytes += 8.0 * (double)lv.nf * (double)g->md.ncells * (src ? 3.0 : 2.0);
+        const double by = 8.0 * (double)lv.nf * (double)g->md.ncells * (src ? 3.0 : 2.0);
+        t.bytes += by;
+        t.ev_level.push_back(lv.level);
+        t.ev_bytes.push_back(by);
     }
 }
 
@@ -986,6 +1162,8 @@ struct TimedRegion {   // HIP-event bracket of the finest-level operator applies
         }
         HIPCHK(hipEventRecord(t.pool[t.used].first, c->stream));
         t.bytes += bytes;
+        t.ev_level.push_back(lv.level);
+        t.ev_bytes.push_back(bytes);
     }
     void stop()
     {
@@ -1010,8 +1188,10 @@ void apply_then_sum(hmg_grid *g, const LevelDev &lv, ApplyArgs a, bool fused, in
     hmg_ctx *c = g->ctx;
     const Launch &L = c->L;
     set_slab(g, lv);
+    ensure_weight_cache(g);
     // algorithmic HBM streams of this launch: x in, out, + src, + x2 (p_old), + xout (p), + xacc (x read and write)
-    const double streams = 1.0 + (a.out ? 1.0 : 0.0) + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) +
+    // (flags bit 7: x is a zero that is not read)
+    const double streams = ((a.flags & 128) ? 0.0 : 1.0) + (a.out ? 1.0 : 0.0) + (a.src ? 1.0 : 0.0) + (a.x2 ? 1.0 : 0.0) + (a.xout ? 1.0 : 0.0) +
                            (a.xacc ? 2.0 : 0.0) + (a.x3 ? 1.0 : 0.0) + (a.xcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0) +
                            (a.rcoarse ? (double)lv.nf_coarse / (double)lv.nf : 0.0);
     TimedRegion tr(g, lv, 8.0 * (double)lv.nf * (double)g->md.ncells * streams);
@@ -1171,9 +1351,14 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             a.lambda = g->lambda;
             a.x = r->d;
             const bool lazy_dead = dead && defer_x && lazy && i > 0;
+            // the same dead step when nobody defers the x-updates (a post-smoother below the finest level inside hmg_vcycle, of
+            // which only x is read): p_i is formed in LDS only, neither p nor x is written by the apply (16 B/DOF instead of 40),
+            // and one pass does both x-updates, p_i formed on the fly (32 B/DOF instead of 24): 48 instead of 64 B/DOF, x the
+            // same to the last bit (round 4, option lazy_post)
+            const bool lazy_x2 = dead && !defer_x && g->ctx->lazy_post && i > 0;
             a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
-            a.xout = (i == 0 && swap_rp) || lazy_dead ? nullptr : p->d;   // (swap_rp: r_0 itself becomes p_0)
-            a.xacc = i == 0 || lazy_dead ? nullptr : x->d;                // x += alpha_{i-1} p_{i-1}
+            a.xout = (i == 0 && swap_rp) || lazy_dead || lazy_x2 ? nullptr : p->d;   // (swap_rp: r_0 itself becomes p_0)
+            a.xacc = i == 0 || lazy_dead || lazy_x2 ? nullptr : x->d;     // x += alpha_{i-1} p_{i-1}
             a.a_num = other;                                              // rs_{i-1} (after the swap below)
             a.a_den = S_PAP;                                              // p_{i-1}.Ap_{i-1}: still the old value here
             a.out = dead ? nullptr : Ap->d;
@@ -1182,6 +1367,11 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             a.flags = 1;
             // (the kernels above read the previous p.Ap from S_PAP; the reduction that overwrites it is enqueued
             //  behind them on the same stream)
+            if (lazy_x2) {
+                apply_then_sum(g, lv, a, true, S_PAP2, -1);        // (S_PAP keeps the previous step's p.Ap, as below)
+                launch_cg_x2_update(L, x->d, p->d, r->d, n, other, S_PAP, cur, other, cur, S_PAP2);
+                return none;
+            }
             if (lazy_dead) {
                 // p.Ap of this step goes to its own slot: S_PAP still holds the previous step's, which the caller
                 // needs for the first of the two pending x-updates
@@ -1967,6 +2157,9 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_unblocked = 0;
     c->L.persistent_waves = 32 * (int64_t)c->L.num_cu;
     c->L.cell_order = 1;
+    c->L.apply_wave = 1;    // level 5: one wave per cell where the class-weight cache exists (hmg_apply_wave.hip)
+    c->L.wave_grid = 16 * (int64_t)c->L.num_cu;
+    c->L.n_wave_launches = &c->wave_launches;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
     {
         LifetimeLock lock(lifetime_mutex());
@@ -1992,6 +2185,16 @@ int hmg_ctx_sync(hmg_ctx *ctx)
     HMG_END
 }
 
+int64_t hmg_ctx_counter(hmg_ctx *ctx, const char *name)
+{
+    if (!ctx || !name) return -1;
+    const std::string n(name);
+    if (n == "wave_launches") return ctx->wave_launches;
+    if (n == "comm_calls") return ctx->comm_calls;
+    if (n == "comm_nranks") return ctx->comm ? ctx->comm_nranks : 0;     // as the RCCL communicator was created; 0: none
+    return -1;
+}
+
 int hmg_ctx_release_memory(hmg_ctx *ctx)
 {
     HMG_TRY
@@ -2012,6 +2215,12 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_unblocked = value != 0;
     else if (n == "apply_wg512")
         ctx->L.apply_wg512 = value != 0;
+    else if (n == "apply_wave")            // 1 = default; 0: level 5 keeps the 256-thread kernel (A/B knob)
+        ctx->L.apply_wave = value != 0;
+    else if (n == "wave_grid")             // persistent waves per CU of the one-wave apply (default 16: what the LDS holds)
+        ctx->L.wave_grid = std::max<int64_t>(1, value) * (int64_t)ctx->L.num_cu;
+    else if (n == "wave_grid_total")       // ... as an absolute number of waves (tests: fewer waves than cells)
+        ctx->L.wave_grid = std::max<int64_t>(1, value);
     else if (n == "cell_order")            // 1 = default: XCD-aware cell order of the register-blocked full-grid apply launches
         ctx->L.cell_order = value != 0;
     else if (n == "persistent_waves")        // per CU; 0 = one workgroup per cell (dev / A-B knob)
@@ -2040,6 +2249,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->fold_faces = value != 0;
     else if (n == "lean_post")
         ctx->lean_post = value != 0;
+    else if (n == "lazy_post")
+        ctx->lazy_post = value != 0;
     else if (n == "prolong_in_image" || n == "prolong_gather")   // (prolong_gather: the option's name in round 2)
         ctx->prolong_in_image = value != 0;
     else if (n == "overlap_min_doubles")
@@ -2056,6 +2267,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->timer.used = 0;
         ctx->timer.bytes = 0.0;
         ctx->timer.launches = 0;
+        ctx->timer.ev_level.clear();
+        ctx->timer.ev_bytes.clear();
     }
     else
         throw std::runtime_error("unknown option: " + n);
@@ -2103,6 +2316,28 @@ int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, doub
     *launches = ctx->timer.launches;
     *total_ms = ms;
     *total_bytes = ctx->timer.bytes;
+    HMG_END
+}
+
+int hmg_ctx_apply_timing_level(hmg_ctx *ctx, int level, int64_t *launches, double *total_ms, double *total_bytes)
+{
+    HMG_TRY
+    need(ctx && launches && total_ms && total_bytes, "null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const ApplyTimer &tm = ctx->timer;
+    double ms = 0.0, by = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i < tm.used && i < tm.ev_level.size(); ++i) {
+        if (tm.ev_level[i] != level) continue;
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, tm.pool[i].first, tm.pool[i].second));
+        ms += t;
+        by += tm.ev_bytes[i];
+        n += 1;
+    }
+    *launches = n;
+    *total_ms = ms;
+    *total_bytes = by;
     HMG_END
 }
 

@@ -47,7 +47,19 @@ struct LevelDev {
     const uint16_t *rs_lp;         // [size of ridx] or null (levels restricted by the slab kernel: stencil order above)
     const int32_t *rptr, *ridx;    // [nf_coarse+1], [..] (level > 1)
     const double *dphi;            // [3*nf]
+    // one-wave-per-cell apply of level 5 (k_apply_wave in hmg_apply_wave.hip): per-lane tables, loaded once per wave
+    const uint32_t *wave_tab;      // [WAVE_TAB_ROWS * 64] addressing words of the lane's surface runs and interior blocks
+    const uint32_t *wave_lpos;     // [8 * 64]  LDS byte offsets of the lane's 16 slots, two per word
+    const uint32_t *wave_par;      // [16 * 64] lattice positions of the two parents of the lane's 16 slots (a | b << 16)
+    const uint32_t *wave_cl;       // [3 * 64]  LDS byte offset of the lane's coarse slots (even lattice nodes of the image)
+    const uint32_t *wave_rs;       // [192 * 8] per coarse slot: 15 lattice positions (u16) of its restriction sum + their number
+    // class-weight cache (hmg_grid_set_operator): W[cell class][sign of alpha][entity class][16] = sum_t ctab * scale_t
+    const double *wcache;          // null: not available on this level
 };
+
+constexpr int WAVE_TAB_ROWS = 15;
+constexpr int WAVE_ROW = 16;                  // doubles per class row of the weight cache (15 taps + 1 pad: 128-B rows)
+constexpr int WAVE_WSTRIDE = 15 * WAVE_ROW;   // doubles per (cell class, sign)
 
 // Rolling-window tables of k_apply_slab (cells larger than the LDS), one set per such level.
 struct SlabTables {
@@ -78,6 +90,10 @@ struct MeshDev {
     const int32_t *cell_perm;                     // option cell_order: workgroup b of a full-grid register-blocked apply works on cell_perm[b]
     int64_t ncells_cut, ncells_inner;
     const uint8_t *mult;         // 16 per cell: number of copies of each entity (bit order of the masks)
+    // class-weight cache: cells with bitwise equal coefficient rows share a class (checkerboards: <= 48); null = no cache
+    const int32_t *cell_class;
+    int nclasses;
+    double wc_lambda;            // the lambda the cached weights were formed with
     double *blockpart;           // 2 per cell: scratch for the fused apply's block sums
     // slab decomposition of the finest level when one cell exceeds the LDS (set per launch by the host)
     SlabTables slab;             // set per level before an apply of a level whose cell exceeds the LDS
@@ -140,6 +156,9 @@ struct Launch {
     int apply_wg512;      // 1 (default): cells that would take the 1024-thread register-blocked instantiation take the 512-thread one:
                           // three workgroups (three columns in flight) per CU instead of two
     int cell_order;       // 1 (default): full-grid register-blocked apply launches walk the cells XCD by XCD (MeshDev::cell_perm)
+    int apply_wave;       // 1 (default): level 5 takes the one-wave-per-cell kernel where the class-weight cache exists
+    int64_t wave_grid;    // its grid: waves resident at once (16 per CU)
+    int64_t *n_wave_launches;   // counts its launches (hmg_ctx_counter "wave_launches"; tests check that the path is taken)
     int64_t persistent_waves;   // grid of the one-wave apply instantiations (default 32 per CU: what is resident at once); they
                           // loop over the cells.  Larger than the number of cells = one workgroup per cell
 };
@@ -156,6 +175,11 @@ bool apply_restricts(const Launch &L, const LevelDev &lv);
 void launch_apply_fused_kernel(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);
 void launch_apply_fused_reduce(const Launch &L, const MeshDev &mesh, int slot_pap, int slot_rr);
 void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh, ApplyArgs a);
+// one-wave-per-cell path (hmg_apply_wave.hip): can this launch take it / launch it (a.scal, a.mult, a.blockpart filled in)
+bool apply_wave_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
+void launch_apply_wave(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
+// W[class][sign][entity class][16] for every distinct coefficient row (coef_rep: 8 doubles per class)
+void launch_weight_cache(const Launch &L, const LevelDev &lv, const double *coef_rep, int nclasses, double lambda, double *wcache);
 
 // which: 0 everything; 1 only the cut edge / node groups (and cut face pairs); 2 everything else (faces, non-cut groups)
 // faces = false leaves the non-cut shared faces alone (their sum then rides in launch_cg_rupdate_faces)
@@ -191,6 +215,9 @@ void launch_cg_rupdate_faces(const Launch &L, const LevelDev &lv, const MeshDev 
 // x += (scal[a_num]/scal[a_den]) p; with_p: p = r + (scal[s_num]/scal[s_den]) p
 void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
                          int s_num, int s_den, int with_p);
+// x = (x + (scal[a_num]/scal[a_den]) p) + (scal[c_num]/scal[c_den]) (r + (scal[b_num]/scal[b_den]) p)
+void launch_cg_x2_update(const Launch &L, double *x, const double *p, const double *r, int64_t n, int a_num, int a_den, int b_num,
+                         int b_den, int c_num, int c_den);
 // beta = scal[s_num]/scal[s_den]; p = r + beta p
 void launch_cg_pupdate(const Launch &L, double *p, const double *r, int64_t n, int s_num, int s_den);
 

@@ -325,7 +325,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             for (int q = 0; q < SPT; ++q) {
                 const int t = tid + q * NT;
                 if (t < nf) {
-                    const double v = xv[q] + beta * x2v[q];
+                    const double v = axpy1(beta, x2v[q], xv[q]);
                     rr += v * v;
                     xs[lp[q]] = v;
                 }
@@ -366,13 +366,13 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     double v = xv[q];
                     if (FUSED) {
                         if (!cgather && ccol) v = prolong(v, pw[q]);
-                        if (xac) xac[t] = xav[q] + ax * x2v[q];
+                        if (xac) xac[t] = axpy1(ax, x2v[q], xav[q]);
                         if (x3c) {
-                            const double t1 = v + ax * x2v[q];
-                            const double p2 = xav[q] + beta * x2v[q];
-                            v = t1 + c2 * p2;
+                            const double t1 = axpy1(ax, x2v[q], v);
+                            const double p2 = axpy1(beta, x2v[q], xav[q]);
+                            v = axpy1(c2, p2, t1);
                         } else if (x2c)
-                            v = v + beta * x2v[q];
+                            v = axpy1(beta, x2v[q], v);
                         if (xoc) xoc[t] = v;
                         if (!RS) rr += v * v;      // (RS: the local residual -- nobody asks for its reductions)
                     }
@@ -386,13 +386,13 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             if (FUSED) {
                 const double pv = x2c ? x2c[t] : 0.0;
                 if (!cgather && ccol) v = prolong(v, lv.par32[t]);
-                if (xac) xac[t] = xac[t] + ax * pv;
+                if (xac) xac[t] = axpy1(ax, pv, xac[t]);
                 if (x3c) {
-                    const double t1 = v + ax * pv;
-                    const double p2 = x3c[t] + beta * pv;
-                    v = t1 + c2 * p2;
+                    const double t1 = axpy1(ax, pv, v);
+                    const double p2 = axpy1(beta, pv, x3c[t]);
+                    v = axpy1(c2, p2, t1);
                 } else if (x2c)
-                    v = v + beta * pv;
+                    v = axpy1(beta, pv, v);
                 if (xoc) xoc[t] = v;
                 rr += v * v;
             }
@@ -765,13 +765,13 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
                     const int t = (int)(wd[q] >> 16);
                     double val = xv[q];
                     if (FUSED) {
-                        if (xac) xac[t] = xav[q] + ax * x2v[q];
+                        if (xac) xac[t] = axpy1(ax, x2v[q], xav[q]);
                         if (x3c) {
-                            const double t1 = val + ax * x2v[q];
-                            const double p2 = xav[q] + beta * x2v[q];
-                            val = t1 + c2 * p2;
+                            const double t1 = axpy1(ax, x2v[q], val);
+                            const double p2 = axpy1(beta, x2v[q], xav[q]);
+                            val = axpy1(c2, p2, t1);
                         } else if (x2c)
-                            val = val + beta * x2v[q];
+                            val = axpy1(beta, x2v[q], val);
                         if (xoc) xoc[t] = val;
                         rr += val * val;
                     }
@@ -944,6 +944,13 @@ template <int DIM, bool FUSED, bool WD = false>
 static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a)
 {
     const size_t lds = apply_lds_bytes(lv);
+    if constexpr (DIM == 3 && !WD) {
+        // level 5: one wave per cell, class weights from the cache (hmg_apply_wave.hip)
+        if (apply_wave_ok(L, lv, mesh, a, FUSED)) {
+            launch_apply_wave(L, lv, mesh, a, FUSED);
+            return;
+        }
+    }
     if (lds > 160 * 1024) {
         if (DIM != 3 || !mesh.slab.head) throw std::runtime_error("operator apply: cell does not fit the LDS");
         auto kern = k_apply_slab<3, 1024, FUSED, WD>;
@@ -1490,11 +1497,11 @@ __global__ void __launch_bounds__(SB) k_axpy(double a, const double *__restrict_
         double2 *y2 = reinterpret_cast<double2 *>(y);
         const double2 xv = reinterpret_cast<const double2 *>(x)[i];
         double2 yv = y2[i];
-        yv.x += a * xv.x;
-        yv.y += a * xv.y;
+        yv.x = axpy1(a, xv.x, yv.x);
+        yv.y = axpy1(a, xv.y, yv.y);
         y2[i] = yv;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] += a * x[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = axpy1(a, x[n - 1], y[n - 1]);
 }
 
 __global__ void __launch_bounds__(SB) k_xpby(const double *__restrict__ r, double b, double *p, int64_t n)
@@ -1504,11 +1511,11 @@ __global__ void __launch_bounds__(SB) k_xpby(const double *__restrict__ r, doubl
         double2 *p2 = reinterpret_cast<double2 *>(p);
         const double2 rv = reinterpret_cast<const double2 *>(r)[i];
         double2 pv = p2[i];
-        pv.x = rv.x + b * pv.x;
-        pv.y = rv.y + b * pv.y;
+        pv.x = axpy1(b, pv.x, rv.x);
+        pv.y = axpy1(b, pv.y, rv.y);
         p2[i] = pv;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + b * p[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = axpy1(b, p[n - 1], r[n - 1]);
 }
 
 __global__ void __launch_bounds__(SB)
@@ -1560,18 +1567,18 @@ k_cg_update(double *x, double *r, const double *__restrict__ p, const double *__
         double2 *r2 = reinterpret_cast<double2 *>(r);
         double2 xv = x2[i], rv = r2[i];
         const double2 pv = reinterpret_cast<const double2 *>(p)[i], qv = reinterpret_cast<const double2 *>(q)[i];
-        xv.x += alpha * pv.x;
-        xv.y += alpha * pv.y;
-        rv.x += (-alpha) * qv.x;
-        rv.y += (-alpha) * qv.y;
+        xv.x = axpy1(alpha, pv.x, xv.x);
+        xv.y = axpy1(alpha, pv.y, xv.y);
+        rv.x = axpy1(-alpha, qv.x, rv.x);
+        rv.y = axpy1(-alpha, qv.y, rv.y);
         x2[i] = xv;
         r2[i] = rv;
         acc += rv.x * rv.x;
         acc += rv.y * rv.y;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        x[n - 1] += alpha * p[n - 1];
-        double rv = r[n - 1] + (-alpha) * q[n - 1];
+        x[n - 1] = axpy1(alpha, p[n - 1], x[n - 1]);
+        double rv = axpy1(-alpha, q[n - 1], r[n - 1]);
         r[n - 1] = rv;
         acc += rv * rv;
     }
@@ -1592,14 +1599,14 @@ k_cg_rupdate(const double *r, double *rout, const double *__restrict__ q, int64_
     if (i < (n >> 1)) {
         double2 rv = reinterpret_cast<const double2 *>(r)[i];
         const double2 qv = reinterpret_cast<const double2 *>(q)[i];
-        rv.x += (-alpha) * qv.x;
-        rv.y += (-alpha) * qv.y;
+        rv.x = axpy1(-alpha, qv.x, rv.x);
+        rv.y = axpy1(-alpha, qv.y, rv.y);
         reinterpret_cast<double2 *>(rout)[i] = rv;
         acc += rv.x * rv.x;
         acc += rv.y * rv.y;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        double rv = r[n - 1] + (-alpha) * q[n - 1];
+        double rv = axpy1(-alpha, q[n - 1], r[n - 1]);
         rout[n - 1] = rv;
         acc += rv * rv;
     }
@@ -1643,14 +1650,14 @@ k_cg_rupdate_faces(const double *r, double *rout, const double *__restrict__ q, 
     if (i < (n >> 1)) {
         double2 rv = reinterpret_cast<const double2 *>(r)[i];
         const double2 qv = reinterpret_cast<const double2 *>(q)[i];
-        rv.x += (-alpha) * summed(2 * i, qv.x);
-        rv.y += (-alpha) * summed(2 * i + 1, qv.y);
+        rv.x = axpy1(-alpha, summed(2 * i, qv.x), rv.x);
+        rv.y = axpy1(-alpha, summed(2 * i + 1, qv.y), rv.y);
         reinterpret_cast<double2 *>(rout)[i] = rv;
         acc += rv.x * rv.x;
         acc += rv.y * rv.y;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        double rv = r[n - 1] + (-alpha) * summed(n - 1, q[n - 1]);
+        double rv = axpy1(-alpha, summed(n - 1, q[n - 1]), r[n - 1]);
         rout[n - 1] = rv;
         acc += rv * rv;
     }
@@ -1672,19 +1679,46 @@ k_cg_xp_update(double *x, double *p, const double *__restrict__ r, int64_t n, co
         double2 xv = x2[i], pv = p2[i];
         double2 rv = make_double2(0.0, 0.0);
         if (with_p) rv = reinterpret_cast<const double2 *>(r)[i];
-        xv.x += alpha * pv.x;
-        xv.y += alpha * pv.y;
+        xv.x = axpy1(alpha, pv.x, xv.x);
+        xv.y = axpy1(alpha, pv.y, xv.y);
         x2[i] = xv;
         if (with_p) {
-            pv.x = rv.x + beta * pv.x;
-            pv.y = rv.y + beta * pv.y;
+            pv.x = axpy1(beta, pv.x, rv.x);
+            pv.y = axpy1(beta, pv.y, rv.y);
             p2[i] = pv;
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        x[n - 1] += alpha * p[n - 1];
-        if (with_p) p[n - 1] = r[n - 1] + beta * p[n - 1];
+        x[n - 1] = axpy1(alpha, p[n - 1], x[n - 1]);
+        if (with_p) p[n - 1] = axpy1(beta, p[n - 1], r[n - 1]);
     }
+}
+
+// two CG x-updates at once, the second direction formed on the fly (a post-smoother's dead last step below the finest level,
+// see smooth()): x = (x + (scal[a_num]/scal[a_den]) p) + (scal[c_num]/scal[c_den]) (r + (scal[b_num]/scal[b_den]) p) -- the three
+// roundings of x += alpha_0 p_0; p_1 = r + beta p_0; x += alpha_1 p_1 done one after the other (k_apply's x3 mode does the same)
+__global__ void __launch_bounds__(SB)
+k_cg_x2_update(double *x, const double *__restrict__ p, const double *__restrict__ r, int64_t n, const double *__restrict__ scal,
+               int a_num, int a_den, int b_num, int b_den, int c_num, int c_den)
+{
+    const double ax = scal[a_num] / scal[a_den];
+    const double beta = scal[b_num] / scal[b_den];
+    const double c2 = scal[c_num] / scal[c_den];
+    const int64_t i = (int64_t)blockIdx.x * SB + threadIdx.x;
+    auto upd = [&](double xv, double pv, double rv) {
+        const double t1 = axpy1(ax, pv, xv);
+        const double p2 = axpy1(beta, pv, rv);
+        return axpy1(c2, p2, t1);
+    };
+    if (i < (n >> 1)) {
+        double2 *x2 = reinterpret_cast<double2 *>(x);
+        double2 xv = x2[i];
+        const double2 pv = reinterpret_cast<const double2 *>(p)[i], rv = reinterpret_cast<const double2 *>(r)[i];
+        xv.x = upd(xv.x, pv.x, rv.x);
+        xv.y = upd(xv.y, pv.y, rv.y);
+        x2[i] = xv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[n - 1] = upd(x[n - 1], p[n - 1], r[n - 1]);
 }
 
 __global__ void __launch_bounds__(SB)
@@ -1696,11 +1730,11 @@ k_cg_pupdate(double *p, const double *__restrict__ r, int64_t n, const double *_
         double2 *p2 = reinterpret_cast<double2 *>(p);
         const double2 rv = reinterpret_cast<const double2 *>(r)[i];
         double2 pv = p2[i];
-        pv.x = rv.x + beta * pv.x;
-        pv.y = rv.y + beta * pv.y;
+        pv.x = axpy1(beta, pv.x, rv.x);
+        pv.y = axpy1(beta, pv.y, rv.y);
         p2[i] = pv;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + beta * p[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = axpy1(beta, p[n - 1], r[n - 1]);
 }
 
 static void finalize(const Launch &L, int nb, int slot)
@@ -1812,6 +1846,16 @@ void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r,
     check_grid(nb);
     hipLaunchKernelGGL(k_cg_xp_update, dim3((unsigned)nb), dim3(SB), 0, L.stream, x, p, r, n, L.scal, a_num, a_den, s_num,
                        s_den, with_p);
+    check_launch();
+}
+
+void launch_cg_x2_update(const Launch &L, double *x, const double *p, const double *r, int64_t n, int a_num, int a_den, int b_num,
+                         int b_den, int c_num, int c_den)
+{
+    const int64_t nb = stream_blocks(n);
+    check_grid(nb);
+    hipLaunchKernelGGL(k_cg_x2_update, dim3((unsigned)nb), dim3(SB), 0, L.stream, x, p, r, n, L.scal, a_num, a_den, b_num, b_den,
+                       c_num, c_den);
     check_launch();
 }
 

@@ -23,6 +23,13 @@ constexpr int WSZ = 232;   // LDS doubles reserved for the class weight table (>
 constexpr int WSZ_RB = 64; // ... of the register-blocked instantiations: only the corners' rows (4 x 15) live in LDS.  With it a
                            // level-6 cell takes 53 192 B: three workgroups per CU (3 x 53 248 <= 160 KB)
 
+// The vector updates of the CG smoother (x += alpha p, p = r + beta p, r -= alpha q) are ONE rounding each, everywhere: the same
+// update is done by different kernels depending on which folds are on (the load phase of an apply, a streaming kernel, both
+// pending updates at once), and the library promises the same bits from all of them.  Left to the backend's contraction, a
+// product hoisted in front of a test of an optional pointer became a separate multiply in some instantiations (round 4: the
+// one-wave level-4 kernel rounded x += alpha p twice, k_cg_xp_update once).
+__device__ __forceinline__ double axpy1(double a, double x, double y) { return __builtin_fma(a, x, y); }   // a x + y
+
 // ---------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------

@@ -61,7 +61,11 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * p-update and, below the top level, everything of the last CG step but x += alpha p; x of every level and r of the
  * top level are unchanged bit for bit, p / Ap (and r below the top level) are scratch on return, as they are for the
  * reference's own callers: the next smoothing_steps! overwrites them before reading, src/multigrid.jl:46-50;
- * 0 = they hold what the reference leaves), "prolong_in_image" (1 = default: on level 6 the folded prolongation stages the
+ * 0 = they hold what the reference leaves), "lazy_post" (1 = default: below the top level the post-smoother's dead last step
+ * writes nothing -- its direction is formed in LDS for the apply and again on the fly by the one pass that does both pending
+ * x-updates; x unchanged bit for bit), "apply_wave" (1 = default: cells of 969 nodes -- 3D level 5 -- are applied by one WAVE
+ * per cell with the class weights taken from a cache that hmg_grid_set_operator fills, hmg_apply_wave.hip; 0 = the 256-thread
+ * workgroup kernel; taken only where the mesh has at most 1024 distinct coefficient rows and |alpha| = 1), "prolong_in_image" (1 = default: on level 6 the folded prolongation stages the
  * coarse column at the even nodes of the LDS lattice image itself instead of in LDS of its own behind it, which would cost
  * the third resident workgroup; "prolong_gather", the option's round-2 name, is still accepted), "fold_restrict" (1 = default:
  * inside hmg_vcycle the local residual of levels 6 and 5 restricts itself in its kernel's epilogue and is not stored; the
@@ -82,6 +86,11 @@ int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value);
 /* HIP-event timing of the operator-apply launches of levels >= the value given to option "time_apply"
  * (0 switches it off; setting it resets the counters).  Synchronises the stream. */
 int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, double *total_bytes);
+/* ... the same, only the launches of one level ("time_apply" = 1 times every level). */
+int hmg_ctx_apply_timing_level(hmg_ctx *ctx, int level, int64_t *launches, double *total_ms, double *total_bytes);
+/* diagnostic counters: "wave_launches" (launches of the one-wave-per-cell level-5 apply, hmg_apply_wave.hip),
+   "comm_calls", "comm_nranks" (ranks of the RCCL communicator made by hmg_comm_init, 0 without one); -1 for an unknown name.  No counterpart in the reference. */
+int64_t hmg_ctx_counter(hmg_ctx *ctx, const char *name);
 
 /* ---- grid: ImplicitFineGrid(base, levels)  (src/implicit_fine_grid.jl:13-18) ------------------ */
 /* Also derives ZeroDirichletConstraint(list_boundary_nodes_edges_faces(base)...)

@@ -32,6 +32,7 @@ mutable struct HipContext
         check(ccall((:hmg_ctx_create, LIB), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h))
         finalizer(c -> ccall((:hmg_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), new(h[]))
     end
+    HipContext(h::Ptr{Cvoid}, ::Val{:handle}) = new(h)                   # (an existing handle: see the stream constructor below)
 end
 sync(c::HipContext) = check(ccall((:hmg_ctx_sync, LIB), Cint, (Ptr{Cvoid},), c.h))
 release_memory(c::HipContext) = check(ccall((:hmg_ctx_release_memory, LIB), Cint, (Ptr{Cvoid},), c.h))
@@ -311,5 +312,159 @@ end
 checkerboard_homogenization(n::Int, ElT; backend::Symbol = :cpu, kwargs...) =
     backend == :hip ? checkerboard_homogenization(n, ElT, Val(:hip); kwargs...) :
                       invoke(checkerboard_homogenization, Tuple{Int,Type{<:Homogenization.ElementType}}, n, ElT; kwargs...)
+
+
+# ---- the rest of the C ABI (include/hmg.h): everything the executable Python mirror binds is bound here too -----------
+# tests/test_binding_drift.py holds every `ccall` of this file against the header: name, arity, type class of every argument.
+version() = Int(ccall((:hmg_version, LIB), Cint, ()))
+
+# context: a caller-owned HIP stream, float options, counters, the apply timer, the scalar bank (api.Context)
+function HipContext(device::Integer, stream::Ptr{Cvoid})                 # kernels are enqueued on the caller's stream
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:hmg_ctx_create_on_stream, LIB), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, stream, h))
+    finalizer(c -> ccall((:hmg_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.h), HipContext(h[], Val(:handle)))
+end
+set_option!(c::HipContext, name::String, v::Float64) =
+    check(ccall((:hmg_ctx_set_option_f64, LIB), Cint, (Ptr{Cvoid}, Cstring, Float64), c.h, name, v))
+counter(c::HipContext, name::String) = Int(ccall((:hmg_ctx_counter, LIB), Int64, (Ptr{Cvoid}, Cstring), c.h, name))
+stream(c::HipContext) = ccall((:hmg_ctx_stream, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), c.h)
+scalar_bank(c::HipContext) = ccall((:hmg_ctx_scalar_bank, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), c.h)
+set_scalar_bank!(c::HipContext, device_doubles16::Ptr{Cvoid}) =
+    check(ccall((:hmg_ctx_set_scalar_bank, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, device_doubles16))
+function apply_timing(c::HipContext)                                     # (launches, ms, algorithmic bytes) since "time_apply" was set
+    n, ms, by = Ref{Int64}(0), Ref{Float64}(0.0), Ref{Float64}(0.0)
+    check(ccall((:hmg_ctx_apply_timing, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Float64}, Ref{Float64}), c.h, n, ms, by))
+    (n[], ms[], by[])
+end
+function apply_timing(c::HipContext, level::Integer)                     # ... of one level
+    n, ms, by = Ref{Int64}(0), Ref{Float64}(0.0), Ref{Float64}(0.0)
+    check(ccall((:hmg_ctx_apply_timing_level, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}, Ref{Float64}, Ref{Float64}),
+                c.h, level, n, ms, by))
+    (n[], ms[], by[])
+end
+comm_destroy!(c::HipContext) = check(ccall((:hmg_comm_destroy, LIB), Cint, (Ptr{Cvoid},), c.h))
+function comm_stats(c::HipContext)                                       # (collectives issued, doubles moved)
+    n, d = Ref{Int64}(0), Ref{Int64}(0)
+    check(ccall((:hmg_comm_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), c.h, n, d))
+    (n[], d[])
+end
+
+# grid queries and tables (api.ImplicitFineGrid)
+nnodes_base(g::HipGrid) = Int(ccall((:hmg_grid_nnodes, LIB), Int64, (Ptr{Cvoid},), g.h))
+nlevels_grid(g::HipGrid) = Int(ccall((:hmg_grid_nlevels, LIB), Cint, (Ptr{Cvoid},), g.h))
+ld(g::HipGrid, level) = Int(ccall((:hmg_grid_ld, LIB), Int64, (Ptr{Cvoid}, Cint), g.h, level))
+function table_i32(g::HipGrid, which::String, level::Integer = 1)
+    n = Ref{Int64}(0)
+    check(ccall((:hmg_grid_table_i32, LIB), Cint, (Ptr{Cvoid}, Cint, Cstring, Ptr{Int32}, Int64, Ref{Int64}), g.h, level, which, C_NULL, 0, n))
+    out = zeros(Int32, n[])
+    check(ccall((:hmg_grid_table_i32, LIB), Cint, (Ptr{Cvoid}, Cint, Cstring, Ptr{Int32}, Int64, Ref{Int64}), g.h, level, which, out, n[], n))
+    out
+end
+function table_f64(g::HipGrid, which::String, level::Integer = 1)
+    n = Ref{Int64}(0)
+    check(ccall((:hmg_grid_table_f64, LIB), Cint, (Ptr{Cvoid}, Cint, Cstring, Ptr{Float64}, Int64, Ref{Int64}), g.h, level, which, C_NULL, 0, n))
+    out = zeros(Float64, n[])
+    check(ccall((:hmg_grid_table_f64, LIB), Cint, (Ptr{Cvoid}, Cint, Cstring, Ptr{Float64}, Int64, Ref{Int64}), g.h, level, which, out, n[], n))
+    out
+end
+
+# level vectors over caller-owned device memory (api.DeviceMatrix.wrap): ld(g, level) * ncells(g) doubles
+function HipMatrix(g::HipGrid, level::Int, device_ptr::Ptr{Cvoid})
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:hmg_vec_wrap, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), g.h, level, device_ptr, h))
+    finalizer(v -> ccall((:hmg_vec_destroy, LIB), Cint, (Ptr{Cvoid},), v.h), HipMatrix(h[], g, level))
+end
+device_ptr(v::HipMatrix) = ccall((:hmg_vec_device_ptr, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), v.h)
+
+# out = (src or 0) + alpha A x, optionally constrained, in one kernel (api.apply_ex); the two halves of a V-cycle level
+# (api.vcycle_down / vcycle_up: src/multigrid.jl:100-106 and :112-115); the level-1 solve alone (src/multigrid.jl:74-93)
+function apply_ex!(out::HipMatrix, alpha, ops, x::HipMatrix, src::Union{HipMatrix,Nothing} = nothing; constrain::Bool = false)
+    bind!(x.grid, ops)
+    check(ccall((:hmg_apply_ex, LIB), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                x.grid.h, x.level, alpha, x.h, src === nothing ? C_NULL : src.h, out.h, constrain ? 1 : 0))
+    out
+end
+function vcycle_down!(ops::Vector, levels::Vector{HipState}, k::Int, steps = 2)
+    g = levels[k].x.grid
+    bind!(g, ops, k)
+    check(ccall((:hmg_vcycle_down, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}), g.h, k, steps, handles(levels)))
+end
+function vcycle_up!(ops::Vector, levels::Vector{HipState}, k::Int, steps = 2)
+    g = levels[k].x.grid
+    bind!(g, ops, k)
+    check(ccall((:hmg_vcycle_up, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}), g.h, k, steps, handles(levels)))
+end
+coarse_solve!(x1::HipMatrix, b1::HipMatrix) =
+    check(ccall((:hmg_coarse_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), x1.grid.h, b1.h, x1.h))
+
+# multi-GPU hooks for hosts that bring their own transport (dist.Exchange with backend "torch"; MPI.jl in Julia): the cut
+# tables of a host-side partition analysis, the callbacks of the sum over ranks (C function pointers: @cfunction), buffer
+# sizes and the message list of the sharers-only exchange.  The in-library RCCL communicator needs none of them
+# (comm_init! + the partitioned HipGrid constructor above).
+function set_cut!(g::HipGrid, nglobal::NTuple{3,Int}, face_gid::Vector{Int64}, face_cell_lid::Vector{Int32},
+                  edge_gid::Vector{Int64}, edge_cell_lid::Vector{Int32}, node_gid::Vector{Int64}, node_cell_lid::Vector{Int32})
+    check(ccall((:hmg_grid_set_cut, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int32}, Int64, Ptr{Int64}, Ptr{Int32}, Int64, Ptr{Int64}, Ptr{Int32}),
+                g.h, nglobal[1], nglobal[2], nglobal[3], length(face_gid), face_gid, face_cell_lid, length(edge_gid), edge_gid,
+                edge_cell_lid, length(node_gid), node_gid, node_cell_lid))
+end
+set_exchange!(g::HipGrid, exchange::Ptr{Cvoid}, scalar_sum::Ptr{Cvoid}, user::Ptr{Cvoid}, device_buf::Ptr{Cvoid}, ndoubles::Integer) =
+    check(ccall((:hmg_grid_set_exchange, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+                g.h, exchange, scalar_sum, user, device_buf, ndoubles))
+set_exchange_async!(g::HipGrid, begin_fn::Ptr{Cvoid}, end_fn::Ptr{Cvoid}) =
+    check(ccall((:hmg_grid_set_exchange_async, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), g.h, begin_fn, end_fn))
+set_exchange_p2p!(g::HipGrid, enabled::Bool, p2p::Ptr{Cvoid}, p2p_begin::Ptr{Cvoid}, device_stage::Ptr{Cvoid}, ndoubles::Integer) =
+    check(ccall((:hmg_grid_set_exchange_p2p, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64),
+                g.h, enabled ? 1 : 0, p2p, p2p_begin, device_stage, ndoubles))
+set_overlap!(g::HipGrid, enabled::Bool) = check(ccall((:hmg_grid_set_overlap, LIB), Cint, (Ptr{Cvoid}, Cint), g.h, enabled ? 1 : 0))
+cut_buffer_doubles(g::HipGrid, level::Integer = 0) = Int(ccall((:hmg_grid_cut_buffer_doubles, LIB), Int64, (Ptr{Cvoid}, Cint), g.h, level))
+cut_stage_doubles(g::HipGrid) = Int(ccall((:hmg_grid_cut_stage_doubles, LIB), Int64, (Ptr{Cvoid},), g.h))
+function exchange_messages(g::HipGrid, level::Integer)                   # 4 numbers per message: peer, buffer offset, count, stage offset
+    n = Ref{Int64}(0)
+    check(ccall((:hmg_grid_exchange_messages, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Int64, Ref{Int64}), g.h, level, C_NULL, 0, n))
+    out = zeros(Int64, n[])
+    check(ccall((:hmg_grid_exchange_messages, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Int64, Ref{Int64}), g.h, level, out, n[], n))
+    reshape(out, 4, :)
+end
+# rehearsal of an N-rank partition on fewer GPUs (dist.PartitionedGrid(cut_owner = ...), tests and timing only)
+function HipGrid(ctx::HipContext, implicit::ImplicitFineGrid{dim}, owner::Vector{Int32}, cut_owner::Vector{Int32}, rank::Integer,
+                 nranks::Integer) where {dim}
+    base = base_mesh(implicit)
+    coords, cells = flat_nodes(base), flat_cells(base)
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:hmg_grid_create_partition_rehearsal, LIB), Cint,
+                (Ptr{Cvoid}, Cint, Cint, Int64, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Cint, Cint, Ref{Ptr{Cvoid}}),
+                ctx.h, dim, nlevels(implicit), nnodes(base), coords, nelements(base), cells, owner, cut_owner, rank, nranks, h))
+    finalizer(g -> ccall((:hmg_grid_destroy, LIB), Cint, (Ptr{Cvoid},), g.h),
+              HipGrid{dim}(h[], ctx, implicit, nlevels(implicit), nothing, NaN))
+end
+
+# threaded host setup of the checkerboard driver (driver.checkerboard_mesh / conductivity_per_element, dist.block_owner):
+# the mesh of unit cubes split into simplices in the reference's order (hypercube + ∞-norm ordering,
+# src/examples/homogenized_coefficients.jl:229-236), the conductivity of every element from the cube it lies in (:484-500),
+# the owner rank of every cell of a brick of blocks
+function checkerboard_mesh(dim::Integer, shape::Vector{Int64}, origin::Vector{Float64}; transposed_lookup::Bool = true, ordered::Bool = true)
+    nn, ne = Ref{Int64}(0), Ref{Int64}(0)
+    check(ccall((:hmg_checkerboard_mesh_size, LIB), Cint, (Cint, Ptr{Int64}, Ref{Int64}, Ref{Int64}), dim, shape, nn, ne))
+    coords, cells = zeros(Float64, dim * nn[]), zeros(Int64, (dim + 1) * ne[])
+    check(ccall((:hmg_checkerboard_mesh, LIB), Cint, (Cint, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Int64}),
+                dim, shape, origin, transposed_lookup ? 1 : 0, ordered ? 1 : 0, coords, cells))
+    (reshape(coords, dim, :), reshape(cells, dim + 1, :))
+end
+function conductivity_per_element(dim::Integer, coords::Matrix{Float64}, cells::Matrix{Int64}, grid_shape::Vector{Int64},
+                                  sigma_grid::Array{Float64}, offset::Vector{Float64})
+    sigma = zeros(Float64, dim * size(cells, 2))
+    check(ccall((:hmg_conductivity_per_element, LIB), Cint,
+                (Cint, Int64, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                dim, size(coords, 2), coords, size(cells, 2), cells, grid_shape, sigma_grid, offset, sigma))
+    reshape(sigma, dim, :)
+end
+function block_owner(dim::Integer, coords::Matrix{Float64}, cells::Matrix{Int64}, blocks::Vector{Int64}, width::Real, origin::Vector{Float64})
+    owner = zeros(Int32, size(cells, 2))
+    check(ccall((:hmg_block_owner, LIB), Cint,
+                (Cint, Int64, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Int64}, Float64, Ptr{Float64}, Ptr{Int32}),
+                dim, size(coords, 2), coords, size(cells, 2), cells, blocks, Float64(width), origin, owner))
+    owner
+end
 
 end # module

@@ -5,6 +5,7 @@
 set -e
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r03}; O=$R/gpurun_out/prof_$T; rm -rf $O; mkdir -p $O
+(cd $R && python3 -c "import json, homogenization_jl_amd as h; print(json.dumps(h._lib.fingerprint()))" > $O/fingerprint.json)
 CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-time-to-tolerance"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $CMD > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $CMD > $O/pmc_fetch.log 2>&1

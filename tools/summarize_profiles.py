@@ -33,6 +33,8 @@ def counters(pattern):
         n = r["Kernel_Name"]
         if "k_apply<3, 1024, 7" in n or "k_apply<3, 512, 13" in n:       # the finest level of config 3 (either workgroup shape)
             acc["k_apply_L6_fused" if "true" in n else "k_apply_L6_plain"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        elif "k_apply_wave<" in n or "k_apply<3, 256, 4" in n:             # level 5: one wave per cell (round 4) / the workgroup kernel
+            acc["k_apply_L5"][r["Counter_Name"]].append(float(r["Counter_Value"]))
         elif "k_cg_rupdate" in n:
             acc["k_cg_rupdate"][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
@@ -65,5 +67,11 @@ if f_all:
            "correction": "FETCH_SIZE x2 (gfx950 wide streaming reads, MI355X_MICROARCH.md HBM section), KB -> x1024",
            "source": f"profiles/{tag}_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
                      "bench.py --steps 2 --warmup 1, mean over the finest-level k_apply launches"}
+    # the build the counters were collected on (tools/collect_profiles.sh writes it on the GPU box): bench.py reports the
+    # traffic figure only when the build it runs is this one
+    fp = os.path.join(src, "fingerprint.json")
+    if os.path.exists(fp):
+        rec.update(json.load(open(fp)))
+    rec["algorithmic_bytes_per_launch_then"] = None
     json.dump(rec, open(os.path.join(dst, "apply_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_summary.json")).read()[:3000])
