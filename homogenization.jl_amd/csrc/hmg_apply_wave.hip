@@ -43,8 +43,6 @@ constexpr int WOFF_EDGE = 4, WOFF_FACE = 94, WNEC = 94;
 constexpr int WNQ = 16;            // slots per lane: 15 full rounds of 64 + 9
 constexpr int WVZ = 168;           // doubles in front of the lattice image: class rows 5..14 (edges, corners) x 16 + 8 spare (lanes without a slot write to the last one)
 
-#define HMG_KP(T, p) ((const T __attribute__((address_space(4))) *)(uintptr_t)(p))   // uniform loads -> scalar loads
-
 // a zero the backend cannot see through: OR-ed into a loop-invariant table word it makes everything DECODED from the word
 // belong to the current cell -- otherwise the backend hoists dozens of decoded addresses out of the cell loop and spills them
 // (lessons of the round-2 pipelined kernel) -- while the word itself stays an ordinary loop-invariant value

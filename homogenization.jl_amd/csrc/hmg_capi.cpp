@@ -960,7 +960,7 @@ void build_cell_classes(hmg_grid *g)
     g->md.nclasses = 0;
     for (auto &d : g->ld) d.wcache = nullptr;
     bool any = false;
-    for (const auto &d : g->ld) any = any || d.wave_tab != nullptr;
+    for (const auto &d : g->ld) any = any || d.level >= 2;
     if (!any || g->dim != 3) return;
     const int64_t n = g->cur().ncells;
     struct Key {
@@ -1003,7 +1003,7 @@ void ensure_weight_cache(hmg_grid *g)
     if (!g->md.cell_class || (g->wc_ready && g->wc_lambda == g->lambda)) return;
     for (int l = 0; l < g->nlevels; ++l) {
         LevelDev &D = g->ld[l];
-        if (!D.wave_tab) continue;
+        if (D.level < 2 || D.ncls != 15) continue;           // (every 3D level an operator is applied on: k_apply<.., WC>, k_apply_wave)
         LevelBufs &B = *g->lb[l];
         B.wcache.alloc((size_t)g->nclasses * 2 * WAVE_WSTRIDE);
         launch_weight_cache(g->ctx->L, D, g->d_coef_rep.p, g->nclasses, g->lambda, B.wcache.p);
@@ -2157,6 +2157,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_unblocked = 0;
     c->L.persistent_waves = 32 * (int64_t)c->L.num_cu;
     c->L.cell_order = 1;
+    c->L.weight_cache = 1;  // level 6: class weight rows from the class-weight cache (k_apply<.., WC>)
     c->L.apply_wave = 1;    // level 5: one wave per cell where the class-weight cache exists (hmg_apply_wave.hip)
     c->L.wave_grid = 16 * (int64_t)c->L.num_cu;
     c->L.n_wave_launches = &c->wave_launches;
@@ -2215,6 +2216,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_unblocked = value != 0;
     else if (n == "apply_wg512")
         ctx->L.apply_wg512 = value != 0;
+    else if (n == "weight_cache")          // 1 = default; 0: level 6 combines its class weights per cell (A/B knob)
+        ctx->L.weight_cache = value != 0;
     else if (n == "apply_wave")            // 1 = default; 0: level 5 keeps the 256-thread kernel (A/B knob)
         ctx->L.apply_wave = value != 0;
     else if (n == "wave_grid")             // persistent waves per CU of the one-wave apply (default 16: what the LDS holds)

@@ -128,6 +128,7 @@ struct ApplyArgs {
     const int32_t *cell_list;   // optional: workgroup b works on cell cell_list[b] (ncell_list of them)
     int64_t ncell_list;
     int64_t nwork;         // set by the launcher: work items (cells) of this launch -- one-wave workgroups loop over them
+    const int32_t *cell_class;  // set by the launcher (WC instantiations): the cell's class in the class-weight cache
 };
 
 struct CoarseDev {
@@ -156,6 +157,7 @@ struct Launch {
     int apply_wg512;      // 1 (default): cells that would take the 1024-thread register-blocked instantiation take the 512-thread one:
                           // three workgroups (three columns in flight) per CU instead of two
     int cell_order;       // 1 (default): full-grid register-blocked apply launches walk the cells XCD by XCD (MeshDev::cell_perm)
+    int weight_cache;     // 1 (default): level 6 takes its class weight rows from the class-weight cache where it exists
     int apply_wave;       // 1 (default): level 5 takes the one-wave-per-cell kernel where the class-weight cache exists
     int64_t wave_grid;    // its grid: waves resident at once (16 per CU)
     int64_t *n_wave_launches;   // counts its launches (hmg_ctx_counter "wave_launches"; tests check that the path is taken)

@@ -44,7 +44,16 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
 // WD: instantiation for the driver integrals (flags bit 3); CG: the folded prolongation stages the coarse column at the even nodes
 // of the lattice image itself (flags bit 6; cells that fill a third of the LDS have no room for it behind the image)
 // RS: the results are restricted to the coarser level in the epilogue (ApplyArgs::rcoarse, see the end of the kernel)
-template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false, bool CG = false, bool RS = false>
+// WC (register-blocked instantiations): the class weight rows come from the class-weight cache of hmg_grid_set_operator
+// (LevelDev::wcache, one row set per distinct coefficient row and sign of alpha: hmg_apply_wave.hip) instead of being combined
+// from the class table and the cell's seven scales by every wave: ONE load per lane, requested in front of the column loads, no
+// table terms held across the load phase, no products -- the same weights to the last bit (same products, same order, formed once)
+// LF (fused WC instantiations): the form of the load phase is known at compile time -- 1: one stream in one batch (CG step 0),
+// 2: two streams in one batch, nothing stored (a dead step), 3: the batched general form; 0: decided at run time.  One form per
+// instantiation: the other forms' values do not compete for the 80 registers, and the dead step can take its rows behind the
+// column loads (two whole columns in one batch are 65 registers in flight: with the rows in front it lost 0.5 ms) while the
+// others take them in front.
+template <int DIM, int NT, int SPT, bool FUSED, int RB, bool WD = false, bool CG = false, bool RS = false, bool WC = false, int LF = 0>
 __global__ void __launch_bounds__(NT, NT >= 640 ? 8 : RB && NT == 512 ? 6 : 1)   // 2 x 1024 threads per CU need <= 64 VGPRs, 3 x 512: 80
 k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a)
 {
@@ -71,18 +80,28 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // already issuing their column loads -- the table's L2 latency then overlaps the HBM latency.
     // RB instantiations share no weight table: every wave combines the class rows it needs itself (below, behind its
     // column loads); the cell's coefficients are requested first, one per lane
-    const double cv = RB ? coef[cell * 8 + (tid & 7)] : 0.0;
+    size_t wbase16 = 0;                 // WC: first entry of this cell's row set in the cache (wave-uniform: scalar loads)
+    if constexpr (WC) wbase16 = (size_t)(2 * HMG_KP(int32_t, a.cell_class)[cell] + (a.alpha < 0.0 ? 1 : 0)) * WAVE_WSTRIDE;
+    const double cv = RB && !WC ? coef[cell * 8 + (tid & 7)] : 0.0;
     if (!RB && (tid >= NT - 256 || NT <= 256)) {
-        double s[NTERM];
-        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags);
         const int first = NT <= 256 ? tid : tid - (NT - 256);
         const int step = NT <= 256 ? NT : 256;
+        if constexpr (WC) {
+            // the whole class table of this cell's class from the cache: 225 loads per cell instead of 1575 table terms and as
+            // many products -- for the one-wave workgroups of the small levels the table was most of a cell's work (level 4: 12.6 KB
+            // of table terms per 1.3 KB column)
+            for (int idx = first; idx < lv.ncls * NDIR; idx += step)
+                W[idx] = lv.wcache[wbase16 + (size_t)((idx / NDIR) * WAVE_ROW + idx % NDIR)];
+        } else {
+        double s[NTERM];
+        cell_scales<DIM>(coef + cell * 8, a.alpha, a.lambda, s, a.flags);
         for (int idx = first; idx < lv.ncls * NDIR; idx += step) {
             const double *c = lv.ctab + (size_t)idx * NTERM;
             double w = 0.0;
 #pragma unroll
             for (int t = 0; t < NTERM; ++t) w += c[t] * s[t];
             W[idx] = w;
+        }
         }
     }
     for (int q = tid; q < lv.lds_g0; q += NT) smem[WS + q] = 0.0;
@@ -102,7 +121,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // (vmcnt counts in order: waiting for the rows does not wait for the column) -- two registers live across the load
     // phase -- instead of in an exposed chain of L2 round trips between the load phase and the barrier.  (Fetching the
     // addressing words early as well costs the fused instantiation 60 spilled VGPRs.)
-    constexpr bool EARLY = RB && NT <= 256;
+    constexpr bool EARLY = RB && (NT <= 256 || WC);
     const int wave = tid >> 6, lane = tid & 63;
     const int face = wave / WPF, ft0 = (wave % WPF) * (FI * 64);
     int edge[NE], ebase[NE];
@@ -125,7 +144,36 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     uint32_t dm = 0u;
     const uint32_t *iw = RB ? lv.blk_word : lv.sweep32;
     const uint16_t *is = RB ? lv.blk_slot : lv.sweep_slot;
+    double cwl = 0.0;                   // WC: the last wave's corner weights (60 of them, one per lane)
     auto issue_rows = [&]() {           // class rows (L2-resident table) x the cell's 7 scales, multiplicities, Dirichlet mask
+        if constexpr (WC) {
+            // (wave-uniform words by scalar loads: Dirichlet mask, multiplicities; the lane's weight by one vector load)
+            if (a.flags & 1) {
+                const uint32_t w2 = HMG_KP(uint32_t, dmask)[cell >> 1];
+                dm = (cell & 1) ? w2 >> 16 : w2 & 0xffffu;
+            }
+            if (RB) {
+                int row = 0;
+                if (lane < 15)
+                    row = lane;
+                else if (lane >= 16 && lane < 31)
+                    row = (1 + face) * WAVE_ROW + lane - 16;
+                else if (lane >= 32 && lane < 47 && edge[0] >= 0)
+                    row = (1 + lv.nface + edge[0]) * WAVE_ROW + lane - 32;
+                else if (NE > 1 && lane >= 48 && lane < 63 && edge[NE - 1] >= 0)
+                    row = (1 + lv.nface + edge[NE - 1]) * WAVE_ROW + lane - 48;
+                wv = lv.wcache[wbase16 + row];
+                if (wave == NW - 1) {
+                    const int cl = lane < 60 ? lane : 59;
+                    cwl = lv.wcache[wbase16 + (1 + lv.nface + lv.nedge + cl / 15) * WAVE_ROW + cl % 15];
+                }
+            }
+            if (FUSED && a.mult) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mqr[q] = HMG_KP(uint32_t, a.mult)[cell * 4 + q];
+            }
+            return;
+        }
         dm = (a.flags & 1) ? dmask[cell] : 0u;
         if (RB) {
             int row = 0;
@@ -166,6 +214,14 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         s1 = RB && NPASS < 2 ? 0 : (int)is[tid + NT];
     };
     auto finish_tables = [&]() {
+        if constexpr (WC) {
+            if (RB && wave == NW - 1 && lane < 60) W[lane] = cwl;      // the corners' rows: the only ones in LDS
+            if (FUSED) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mq[q] = a.mult ? mqr[q] : 0x01010101u;
+            }
+            return;
+        }
         if (RB) {
             double sc7[NTERM];
 #pragma unroll
@@ -188,7 +244,14 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             for (int q = 0; q < 4; ++q) mq[q] = a.mult ? __builtin_amdgcn_readfirstlane(mqr[q]) : 0x01010101u;   // (no table: all 1)
         }
     };
-    if (EARLY) issue_rows();
+    // (measured, profiles/r04_experiments.txt: the dead step with its rows in front as well, step 0 with the words of its interior
+    //  blocks in front, the dead step through the general instantiation -- no difference beyond +-0.05 ms per launch)
+    constexpr bool rows_late = WC && LF == 2;
+    // (the one-form instantiations have registers to spare -- 70 of 80 --: their addressing words are requested in front of the
+    //  column as well, so that nothing but the barrier stands between the column's arrival and the evaluation)
+    constexpr bool WEARLY = false;       // (measured: LF == 1 with its words in front goes from 70 to 80 registers + 16 B of scratch)
+    if (EARLY && !rows_late) issue_rows();
+    if (WEARLY) issue_words();
     const double *xc = a.x + cell * lv.ld;
     double rr = 0.0, pap = 0.0;
     {
@@ -249,6 +312,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     pw[q] = lv.par64[t];
                 }
             }
+            if (EARLY) finish_tables();
 #pragma unroll
             for (int q = 0; q < NC; ++q)
                 if (tid + q * NT < lv.nf_coarse) xs[cl2[q]] = cv2[q];
@@ -283,7 +347,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
         // A fused pass that reads nothing but its own column (CG step 0 with r itself as p: no x2 / xacc / x3 / coarse
         // column) takes the whole column in ONE batch like the plain apply -- one memory round trip instead of two.
         // (RS: the local residual with pending CG updates -- never a light pass, never a prolongation)
-        const bool light = !RS && FUSED && NT >= 512 && !x2c && !xac && !x3c && !ccol;   // (level 5, 256 threads: the extra path costs a resident workgroup)
+        const bool light = LF == 1 || (LF == 0 && !RS && FUSED && NT >= 512 && !x2c && !xac && !x3c && !ccol);   // (level 5, 256 threads: the extra path costs a resident workgroup)
         if (FUSED && light) {
             double xv[SPT];
             int lp[SPT];
@@ -308,7 +372,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
             }
         }
         // ... and the dead step of a pre-smoother (reads r and p, forms p_new only in LDS, writes nothing): two streams
-        const bool light2 = !RS && FUSED && NT >= 512 && x2c && !xoc && !xac && !x3c && !ccol;
+        const bool light2 = LF == 2 || (LF == 0 && !RS && FUSED && NT >= 512 && x2c && !xoc && !xac && !x3c && !ccol);
         if (FUSED && light2) {
             double xv[SPT], x2v[SPT];
             int lp[SPT];
@@ -321,6 +385,8 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                     lp[q] = lv.lpos[t];
                 }
             }
+            if (EARLY && rows_late) issue_rows();
+            if (EARLY) finish_tables();
 #pragma unroll
             for (int q = 0; q < SPT; ++q) {
                 const int t = tid + q * NT;
@@ -404,7 +470,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // (scheduling fence: keeps the table prefetch below out of the load phase's register budget -- the
     //  1024-thread variants must stay within 64 VGPRs to keep two workgroups resident per CU)
     __builtin_amdgcn_sched_barrier(0);
-    issue_words();
+    if (!WEARLY) issue_words();
     if (!EARLY) {
         issue_rows();
         finish_tables();
@@ -915,10 +981,17 @@ static void check_apply_bases(const ApplyArgs &a, const MeshDev &mesh)
         throw std::runtime_error("operator apply: the zero-input form exists for the residual with two pending x-updates only");
 }
 
-template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false, bool CG = false, bool RS = false>
+// can this launch take its class weights from the class-weight cache?  (formed for |alpha| = 1, the grid's lambda, the full operator)
+static bool weight_cache_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a)
+{
+    return L.weight_cache && lv.wcache && mesh.cell_class && lv.dim == 3 && lv.ncls == 15 && !(a.flags & (2 | 8 | 16)) &&
+           (a.alpha == 1.0 || a.alpha == -1.0) && a.lambda == mesh.wc_lambda;
+}
+
+template <int DIM, int NT, int SPT, bool FUSED, int RB = 0, bool WD = false, bool CG = false, bool RS = false, bool WC = false, int LF = 0>
 static void launch_apply_generic(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, size_t lds)
 {
-    auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD, CG, RS>;
+    auto kern = k_apply<DIM, NT, SPT, FUSED, RB, WD, CG, RS, WC, LF>;
     if (a.rcoarse && !RS) throw std::runtime_error("operator apply: this instantiation cannot restrict in its epilogue");
     if ((a.flags & 128) && !(FUSED && (RS || RB == 0)))
         throw std::runtime_error("operator apply: this instantiation cannot take a zero input that is not in memory");
@@ -930,6 +1003,8 @@ static void launch_apply_generic(const Launch &L, const LevelDev &lv, const Mesh
     check_apply_bases<FUSED>(a, mesh);
     ApplyArgs b = a;
     b.nwork = nblocks;
+    b.cell_class = WC ? mesh.cell_class : nullptr;
+    if (WC && !weight_cache_ok(L, lv, mesh, a)) throw std::runtime_error("operator apply: class-weight cache not usable for this launch");
     if (L.cell_order && RB && !a.cell_list && !a.ncells_prefix && mesh.cell_perm) {
         b.cell_list = mesh.cell_perm;              // (XCD x walks the x-th eighth of the cells, see upload_mesh)
         b.ncell_list = nblocks;
@@ -977,6 +1052,15 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     if (nt == 0) nt = nf <= 192 ? 64 : nf <= 2048 ? 256 : 1024;
     if (nt <= 64) {
         // (level 4, 165 nodes per wave: three slots per lane loaded as batches, not one dependent round trip per slot)
+        if constexpr (DIM == 3 && !WD) {
+            if (weight_cache_ok(L, lv, mesh, a)) {           // the cell's class table from the class-weight cache
+                if (nf > 64)
+                    launch_apply_generic<DIM, 64, 3, FUSED, 0, false, false, false, DIM == 3>(L, lv, mesh, a, lds);
+                else
+                    launch_apply_generic<DIM, 64, 1, FUSED, 0, false, false, false, DIM == 3>(L, lv, mesh, a, lds);
+                return;
+            }
+        }
         if (nf > 64)
             launch_apply_generic<DIM, 64, 3, FUSED, 0, WD>(L, lv, mesh, a, lds);
         else
@@ -1017,15 +1101,30 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
             if (L.apply_wg512 && lv.nfi <= 512) {
                 // (own instantiation: the in-image staging of the coarse column costs the others registers; it handles the
                 //  residual of the coarse-grid correction only -- no pending CG updates -- and one batch of 13 slots)
-                if (FUSED && DIM == 3 && a.xcoarse && (a.flags & 64) && lv.par64 && lv.clpos && !a.x2 && !a.xacc && !a.x3 &&
-                    lv.nf <= 13 * 512 && lv.nf_coarse <= 2 * 512)
-                    launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0, false, FUSED && DIM == 3>(L, lv, mesh, a,
-                                                                                                      apply_lds_bytes_rb(lv));
-                else if (FUSED && DIM == 3 && a.rcoarse && lv.rs_word && lv.rs_w && !a.xcoarse)   // (own instantiation again)
-                    launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0, false, false, FUSED && DIM == 3>(
-                        L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                const bool cg = FUSED && DIM == 3 && a.xcoarse && (a.flags & 64) && lv.par64 && lv.clpos && !a.x2 && !a.xacc && !a.x3 &&
+                                lv.nf <= 13 * 512 && lv.nf_coarse <= 2 * 512;
+                const bool rs = !cg && FUSED && DIM == 3 && a.rcoarse && lv.rs_word && lv.rs_w && !a.xcoarse;   // (own instantiation again)
+                constexpr int R6 = DIM == 3 ? 6 : 0;
+                constexpr bool F3 = FUSED && DIM == 3;
+                if (DIM == 3 && weight_cache_ok(L, lv, mesh, a)) {      // class weights from the cache (WC), else combined per cell
+                    if (cg)
+                        launch_apply_generic<DIM, 512, 13, FUSED, R6, false, F3, false, DIM == 3>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                    else if (rs)
+                        launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, F3, DIM == 3>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                    else if (FUSED && !a.x2 && !a.xacc && !a.x3 && !a.xcoarse && !a.rcoarse)                 // CG step 0
+                        launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, false, DIM == 3, F3 ? 1 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                    else if (FUSED && a.x2 && !a.xout && !a.xacc && !a.x3 && !a.xcoarse && !a.rcoarse)       // a dead step
+                        launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, false, DIM == 3, F3 ? 2 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                    else
+                        launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, false, DIM == 3>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                    return;
+                }
+                if (cg)
+                    launch_apply_generic<DIM, 512, 13, FUSED, R6, false, F3>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                else if (rs)
+                    launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, F3>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
                 else
-                    launch_apply_generic<DIM, 512, 13, FUSED, DIM == 3 ? 6 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
+                    launch_apply_generic<DIM, 512, 13, FUSED, R6>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
                 return;
             }
         }

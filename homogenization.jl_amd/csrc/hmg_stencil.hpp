@@ -23,6 +23,9 @@ constexpr int WSZ = 232;   // LDS doubles reserved for the class weight table (>
 constexpr int WSZ_RB = 64; // ... of the register-blocked instantiations: only the corners' rows (4 x 15) live in LDS.  With it a
                            // level-6 cell takes 53 192 B: three workgroups per CU (3 x 53 248 <= 160 KB)
 
+// uniform (wave-invariant) loads through the constant address space become scalar loads (s_load_*): results land in SGPRs
+#define HMG_KP(T, p) ((const T __attribute__((address_space(4))) *)(uintptr_t)(p))
+
 // The vector updates of the CG smoother (x += alpha p, p = r + beta p, r -= alpha q) are ONE rounding each, everywhere: the same
 // update is done by different kernels depending on which folds are on (the load phase of an apply, a streaming kernel, both
 // pending updates at once), and the library promises the same bits from all of them.  Left to the backend's contraction, a

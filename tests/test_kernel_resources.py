@@ -12,14 +12,33 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
-# template arguments <DIM, NT, SPT, FUSED, RB, WD, CG, RS> as they appear in the mangled names
+# template arguments <DIM, NT, SPT, FUSED, RB, WD, CG, RS, WC, LF> as they appear in the mangled names
 BUDGET = {
-    "Li3ELi512ELi13ELb0ELi6ELb0ELb0ELb0E": (80, 0),     # level 6, plain apply / residual
-    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb0E": (80, 0),     # level 6, fused CG passes (6 of the 9 finest-level launches)
-    "Li3ELi512ELi13ELb1ELi6ELb0ELb1ELb0E": (80, 0),     # level 6, residual with the coarse-grid correction staged in the image
-    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb1E": (80, 16),    # level 6, local residual with the restriction in its epilogue
-    "Li3ELi256ELi4ELb1ELi4ELb0ELb0ELb0E": (80, 0),      # level 5, fused
-    "Li3ELi256ELi4ELb1ELi4ELb0ELb0ELb1E": (80, 0),      # level 5, restriction in the epilogue
+    # level 6 with the class weights from the cache (WC: what the benchmark runs on a checkerboard)
+    "Li3ELi512ELi13ELb0ELi6ELb0ELb0ELb0ELb1ELi0E": (80, 0),     # plain apply / residual
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb0ELb1ELi0E": (80, 0),     # fused CG passes, general (batched) load phase
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb0ELb1ELi1E": (80, 0),     # ... CG step 0 (one stream, one batch)
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb0ELb1ELi2E": (80, 0),     # ... a dead step (two streams, one batch)
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb1ELb0ELb1ELi0E": (80, 0),     # residual with the coarse-grid correction staged in the image
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb1ELb1ELi0E": (80, 0),     # local residual with the restriction in its epilogue
+    # ... and combined per cell (meshes with more than 1024 distinct coefficient rows, alpha other than +-1)
+    "Li3ELi512ELi13ELb0ELi6ELb0ELb0ELb0ELb0ELi0E": (80, 0),
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb0ELb0ELi0E": (80, 0),
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb1ELb0ELb0ELi0E": (80, 0),
+    "Li3ELi512ELi13ELb1ELi6ELb0ELb0ELb1ELb0ELi0E": (80, 16),
+    "Li3ELi256ELi4ELb1ELi4ELb0ELb0ELb0ELb0ELi0E": (80, 0),      # level 5 workgroup kernel (fallback of the one-wave kernel), fused
+    "Li3ELi256ELi4ELb1ELi4ELb0ELb0ELb1ELb0ELi0E": (80, 0),      # ... restriction in the epilogue
+}
+# k_apply_wave<FUSED, CG, RS, SRC> (hmg_apply_wave.hip): one wave per level-5 cell; 16 waves per CU fit the LDS and leave 128
+# VGPRs, the instantiations that hold a second set of values across the cell run 12 waves per CU with 168 -- none may spill
+# (a spilled table word is reloaded in front of every column load: vmcnt(0) in the middle of the load phase)
+WAVE_BUDGET = {
+    "Lb0ELb0ELb0ELb0E": (128, 0),     # plain apply
+    "Lb0ELb0ELb0ELb1E": (128, 0),     # plain residual
+    "Lb1ELb0ELb0ELb0E": (128, 0),     # fused CG passes (4 of the 6 level-5 launches of a V-cycle)
+    "Lb1ELb0ELb0ELb1E": (168, 0),     # fused with a source vector
+    "Lb1ELb1ELb0ELb1E": (168, 0),     # residual with the coarse-grid correction staged in the image
+    "Lb1ELb0ELb1ELb1E": (168, 0),     # local residual with the restriction in its epilogue
 }
 
 
@@ -35,5 +54,21 @@ def test_hot_instantiations_fit_their_register_budget(tmp_path):
         found[m.group(1)] = (int(m.group(2)), int(m.group(3)))
     for name, (vgprs, scratch) in BUDGET.items():
         assert name in found, f"instantiation {name} not compiled; have {sorted(found)[:5]} ..."
+        assert found[name][0] <= vgprs, (name, found[name])
+        assert found[name][1] <= scratch, (name, found[name])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_wave_kernel_fits_its_register_budget(tmp_path):
+    src = os.path.join(ROOT, "homogenization.jl_amd", "csrc", "hmg_apply_wave.hip")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                          "-o", str(tmp_path / "w.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    found = {}
+    for m in re.finditer(r"Function Name: _ZN3hmg12k_apply_waveI(\w+?)EEvNS_8LevelDev.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)",
+                         out.stderr, re.S):
+        found[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    for name, (vgprs, scratch) in WAVE_BUDGET.items():
+        assert name in found, f"instantiation {name} not compiled; have {sorted(found)}"
         assert found[name][0] <= vgprs, (name, found[name])
         assert found[name][1] <= scratch, (name, found[name])
