@@ -172,6 +172,7 @@ struct hmg_ctx {
     hipStream_t comm_stream = nullptr;       // the overlapped cut exchange runs here
     hipEvent_t ev_packed = nullptr, ev_summed = nullptr;
     int64_t comm_calls = 0, comm_doubles = 0;
+    int64_t small_launches = 0;              // launches of the pipelined small-level apply
     int64_t wave_launches = 0;               // launches of the one-wave-per-cell apply (hmg_ctx_counter)
     // Level-vector memory handed back by hmg_vec_destroy, kept for the next hmg_vec_create of the same size: on this
     // platform hipMalloc of memory the process has freed before costs ~35 ms per GB (tools/dev/alloc_probe.hip: 6 x 10 GB
@@ -2161,6 +2162,8 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_wave = 1;    // level 5: one wave per cell where the class-weight cache exists (hmg_apply_wave.hip)
     c->L.wave_grid = 16 * (int64_t)c->L.num_cu;
     c->L.n_wave_launches = &c->wave_launches;
+    c->L.apply_small = 1;   // levels 2-4: pipelined one-wave kernel (hmg_apply_small.hip)
+    c->L.n_small_launches = &c->small_launches;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
     {
         LifetimeLock lock(lifetime_mutex());
@@ -2191,6 +2194,7 @@ int64_t hmg_ctx_counter(hmg_ctx *ctx, const char *name)
     if (!ctx || !name) return -1;
     const std::string n(name);
     if (n == "wave_launches") return ctx->wave_launches;
+    if (n == "small_launches") return ctx->small_launches;
     if (n == "comm_calls") return ctx->comm_calls;
     if (n == "comm_nranks") return ctx->comm ? ctx->comm_nranks : 0;     // as the RCCL communicator was created; 0: none
     return -1;
@@ -2216,6 +2220,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_unblocked = value != 0;
     else if (n == "apply_wg512")
         ctx->L.apply_wg512 = value != 0;
+    else if (n == "apply_small")           // 1 = default; 0: levels 2-4 keep k_apply<3,64,*> (A/B knob)
+        ctx->L.apply_small = value != 0;
     else if (n == "weight_cache")          // 1 = default; 0: level 6 combines its class weights per cell (A/B knob)
         ctx->L.weight_cache = value != 0;
     else if (n == "apply_wave")            // 1 = default; 0: level 5 keeps the 256-thread kernel (A/B knob)

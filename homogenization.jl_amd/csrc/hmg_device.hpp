@@ -158,6 +158,8 @@ struct Launch {
                           // three workgroups (three columns in flight) per CU instead of two
     int cell_order;       // 1 (default): full-grid register-blocked apply launches walk the cells XCD by XCD (MeshDev::cell_perm)
     int weight_cache;     // 1 (default): level 6 takes its class weight rows from the class-weight cache where it exists
+    int apply_small;      // 1 (default): levels 2-4 (3D, <= 192 nodes per cell) take the pipelined one-wave kernel where the cache exists
+    int64_t *n_small_launches;
     int apply_wave;       // 1 (default): level 5 takes the one-wave-per-cell kernel where the class-weight cache exists
     int64_t wave_grid;    // its grid: waves resident at once (16 per CU)
     int64_t *n_wave_launches;   // counts its launches (hmg_ctx_counter "wave_launches"; tests check that the path is taken)
@@ -180,6 +182,9 @@ void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh,
 // one-wave-per-cell path (hmg_apply_wave.hip): can this launch take it / launch it (a.scal, a.mult, a.blockpart filled in)
 bool apply_wave_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
 void launch_apply_wave(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
+// small 3D levels (hmg_apply_small.hip): one persistent, software-pipelined wave per cell
+bool apply_small_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
+void launch_apply_small(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
 // W[class][sign][entity class][16] for every distinct coefficient row (coef_rep: 8 doubles per class)
 void launch_weight_cache(const Launch &L, const LevelDev &lv, const double *coef_rep, int nclasses, double lambda, double *wcache);
 

@@ -1025,6 +1025,11 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
             launch_apply_wave(L, lv, mesh, a, FUSED);
             return;
         }
+        // levels 2-4: one persistent, software-pipelined wave per cell (hmg_apply_small.hip)
+        if (apply_small_ok(L, lv, mesh, a, FUSED)) {
+            launch_apply_small(L, lv, mesh, a, FUSED);
+            return;
+        }
     }
     if (lds > 160 * 1024) {
         if (DIM != 3 || !mesh.slab.head) throw std::runtime_error("operator apply: cell does not fit the LDS");
