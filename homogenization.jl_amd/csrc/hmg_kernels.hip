@@ -68,6 +68,8 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
     // which waves can be started and by what every start repeats (kernel arguments, LDS allocation), not by the cells'
     // work -- so the launcher starts as many as are resident at once and each walks its share of the cells.  (The body
     // below is not indented for the loop: every other instantiation runs it exactly once.)
+    // (round 4: a persistent loop around the one-form level-6 instantiations LF = 1 / 2 -- 70 VGPRs without it -- still spills 552 /
+    //  672 B per lane: the backend hoists the addresses of every table and column load out of the loop)
     constexpr bool LOOP = NT == 64;
     int64_t blk = blockIdx.x;
     do {

@@ -11,7 +11,7 @@ set -e
 T=${1:-l5seq}
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$T; rm -rf $O; mkdir -p $O
-HMG_OPTIONS=${EXTRA_OPTIONS:-} rocprofv3 --kernel-trace --output-format csv -d $O/w1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-time-to-tolerance --tune-placement 0 > $O/w1.log 2>&1
+HMG_OPTIONS=${EXTRA_OPTIONS:-} rocprofv3 --kernel-trace --output-format csv -d $O/w1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-time-to-tolerance --no-level-report --tune-placement 0 > $O/w1.log 2>&1
 python3 - <<PY | tee $O/sequence.txt
 import csv, glob
 f = glob.glob("$O/w1/*/*kernel_trace.csv")[0]
