@@ -735,6 +735,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
     constexpr int NDIR = DIM == 3 ? 15 : 7;
     constexpr int NTERM = DIM == 3 ? 7 : 4;
     constexpr int HB = FUSED ? 3 : 4;               // loads in flight per thread and stream in the load phase (64-VGPR budget)
+    constexpr int MV = 5;                           // values per thread of the window move (two planes of level 7: <= 4225 nodes)
     extern __shared__ double smem[];
     double *W = smem;
     double *img = smem + WSZ;                       // lds_nodes doubles: [planes k0-1..k1 | zero guard]
@@ -790,18 +791,40 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
         const int k0 = hd[0], ld_off = hd[1], ld_cnt = hd[2], cp_off = hd[3], cp_cnt = hd[4], cp_surf = hd[5];
         const int lo = plane_off(k0 - 1);                           // lattice range held in LDS: [lo, PO(k1 + 1))
         double *xs = img - lo;                                      // xs[L] valid inside that range (+ zero guard)
+        // (round 4) the words of the slab's first batch of loads are requested before the window is rearranged: their L2 round
+        // trip -- the column loads depend on them -- runs behind the move and the zero fill instead of after them
+        uint32_t wd0[HB];
+#pragma unroll
+        for (int q = 0; q < HB; ++q) wd0[q] = st.ld_word[ld_off + q * NT + tid];
         if (sl > 0) {
             __syncthreads();                                        // previous slab fully consumed
             // planes k0-1 and k0 (the last evaluated plane and the upper halo of the previous slab) move to the
             // front of the window; destination below source, ascending chunks, one barrier between a chunk's
             // reads and its writes
             const int cnt = plane_off(k0 + 1) - lo, src = lo - lo_prev;
+            if (cnt <= MV * NT) {
+                // (round 4) every thread takes its share of the two planes into registers, ONE barrier, then writes: the chunked form
+                // below pays a barrier per 1024 values -- five per slab near the base of the cell
+                double mv[MV];
+#pragma unroll
+                for (int c = 0; c < MV; ++c) {
+                    const int q = c * NT + tid;
+                    mv[c] = q < cnt ? img[src + q] : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < MV; ++c) {
+                    const int q = c * NT + tid;
+                    if (q < cnt) img[q] = mv[c];
+                }
+            } else {
             const int nchunk = (cnt + NT - 1) / NT;
             for (int c = 0; c < nchunk; ++c) {
                 const int q = c * NT + tid;
                 const double v = q < cnt ? img[src + q] : 0.0;
                 __syncthreads();
                 if (q < cnt) img[q] = v;
+            }
             }
         }
         for (int q = (sl > 0 ? plane_off(k0 + 1) - lo : 0) + tid; q < st.lds_nodes; q += NT) img[q] = 0.0;   // stale data + guard
@@ -814,7 +837,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
                 const int v = q0 + q * NT + tid;
-                wd[q] = st.ld_word[ld_off + v];                      // (list is padded: no bounds check)
+                wd[q] = q0 == 0 ? wd0[q] : st.ld_word[ld_off + v];   // (list is padded: no bounds check)
             }
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
