@@ -245,16 +245,21 @@ void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, dou
 void launch_coarse_gather_rhs(const Launch &L, const CoarseDev &A, const double *u, double *b);
 void launch_coarse_scatter_sol(const Launch &L, const CoarseDev &A, int64_t nnodes, const double *x, double *u);
 void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z,
-                        double *p);   // x=0,r=b,z=r/d,p=z, scal[S_C0]=r.z, scal[S_C2]=b.b, S_DONE = S_ITER = 0
+                        double *p, double zscale = 1.0, double *dcheb = nullptr);   // x=0,r=b,z=r/d,p=z, scal[S_C0]=r.z, scal[S_C2]=b.b, S_DONE = S_ITER = 0
+// polynomial (Chebyshev) preconditioner of the level-1 PCG, see k_coarse_cheb: with dcheb the init / update kernels leave
+// z = d = zscale D^-1 r (the first iterate), launch_coarse_cheb does one more step, the last one leaves the partials of r.z
+void launch_coarse_cheb(const Launch &L, const CoarseDev &A, const double *r, const double *zin, double *zout, double *d, double c1,
+                        double c2, int last);
+void launch_coarse_rz_from_cheb(const Launch &L, const CoarseDev &A);
 // one iteration = launch_coarse_direction + launch_coarse_update; r.z lives in scal[slot_old] -> scal[slot_new] (S_C0 / S_C3,
 // exchanged by the caller every iteration), the other dot products stay in block partials that the consumer kernel sums itself
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
-                          const double *q, int slot_old);   // alpha = rz/p.q; partials of r.z (new), r.r
+                          const double *q, int slot_old, double zscale = 1.0, double *dcheb = nullptr);   // alpha = rz/p.q; partials of r.z (new), r.r
 void launch_coarse_residual_norm(const Launch &L, const CoarseDev &A);
 // two-launch iteration: direction (beta, convergence bookkeeping, p = z + beta p, q = A z + beta q, partials of p.q) + update;
 // mode 0 regular, 1 first of a solve, 2 bookkeeping only; count_it: see k_coarse_direction
 void launch_coarse_direction(const Launch &L, const CoarseDev &A, double *p, double *q, const double *z, int slot_old, int slot_new,
-                             double rtol2, int mode, int count_it);   // scal[S_TMP] = r.r of the last update
+                             double rtol2, int mode, int count_it, int rz_from_cheb = 0);   // scal[S_TMP] = r.r of the last update
 
 // b[slot, cell] = dot(dphi[slot], pvec[cell])   (rhs_a xi grad v)
 void launch_rhs_dphi(const Launch &L, const LevelDev &lv, int64_t ncells, const double *pvec, double *b);

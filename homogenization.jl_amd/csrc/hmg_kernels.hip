@@ -2166,17 +2166,19 @@ k_coarse_scatter_sol(const int32_t *__restrict__ interior, int64_t n, const doub
 
 __global__ void __launch_bounds__(256)
 k_coarse_init(CoarseDev A, const double *__restrict__ b, double *x, double *r, double *z, double *p, double *part0,
-              double *part1)
+              double *part1, double zscale, double *dcheb)
 {
+    // zscale, dcheb: polynomial preconditioner (k_coarse_cheb) -- z = d_0 = (1 / theta) D^-1 r is the first Chebyshev iterate
     __shared__ double red[4];
     double rz = 0.0, bb = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
         const double bi = b[i];
-        const double zi = bi / A.diag[i];
+        const double zi = dcheb ? zscale * (bi / A.diag[i]) : bi / A.diag[i];
         x[i] = 0.0;
         r[i] = bi;
         z[i] = zi;
         p[i] = zi;
+        if (dcheb) dcheb[i] = zi;
         rz += bi * zi;
         bb += bi * bi;
     }
@@ -2201,7 +2203,7 @@ k_coarse_init(CoarseDev A, const double *__restrict__ b, double *x, double *r, d
 __global__ void __launch_bounds__(256)
 k_coarse_direction(CoarseDev A, double *p, double *q, const double *__restrict__ z, double *scal, int slot_old, int slot_new,
                    const double *__restrict__ part_rz, const double *__restrict__ part_rr, int nb_upd, double rtol2, int mode,
-                   int count_it, double *part_pq)
+                   int count_it, double *part_pq, int nb_rz)
 {
     __shared__ double red[4];
     __shared__ double bc;
@@ -2211,7 +2213,7 @@ k_coarse_direction(CoarseDev A, double *p, double *q, const double *__restrict__
     if (skip) return;
     double beta = 0.0;
     if (mode != 1) {
-        const double rz_new = sum_partials_all(part_rz, nb_upd, red, &bc);
+        const double rz_new = sum_partials_all(part_rz, nb_rz, red, &bc);   // (polynomial preconditioner: from the last Chebyshev step)
         const double rr = sum_partials_all(part_rr, nb_upd, red, &bc);
         const double rz_old = scal[slot_old];
         beta = rz_old != 0.0 ? rz_new / rz_old : 0.0;
@@ -2248,13 +2250,49 @@ k_coarse_direction(CoarseDev A, double *p, double *q, const double *__restrict__
     if (threadIdx.x == 0) part_pq[blockIdx.x] = sacc;
 }
 
+// One step of the Chebyshev iteration for D^-1 A z = D^-1 r from z_1 = (1 / theta) D^-1 r (Saad, Iterative Methods, Alg. 12.1):
+//   d <- c1 d + c2 D^-1 (r - A zin),  zout = zin + d          (c1 = rho_j rho_j-1, c2 = 2 rho_j / delta: host, launch_coarse_cheb)
+// k - 1 of these between the update and the direction kernel make z = p_{k-1}(D^-1 A) D^-1 r, a symmetric positive definite
+// polynomial preconditioner (the interval [lmax / ratio, lmax] with lmax a Gershgorin bound: the polynomial stays positive on the
+// whole spectrum).  No reductions but the last step's partial sums of r.z: an outer CG iteration costs k + 1 launches for k
+// sparse products, where plain Jacobi-PCG pays two launches and two grid-wide sums per product.  16 lanes per row as in
+// k_coarse_direction.
+__global__ void __launch_bounds__(256)
+k_coarse_cheb(CoarseDev A, const double *__restrict__ r, const double *__restrict__ zin, double *zout, double *d, double c1, double c2,
+              const double *__restrict__ scal, int last, double *part_rz)
+{
+    __shared__ double red[4];
+    if (scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0)) return;
+    const int sub = threadIdx.x & 15;
+    double acc = 0.0;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < A.n; i += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+        const int b = A.rowptr[i], e = A.rowptr[i + 1];
+        double s = 0.0;
+        for (int k = b + sub; k < e; k += 16) s += A.val[k] * zin[A.colidx[k]];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+        if (sub == 0) {
+            const double ri = r[i];
+            const double di = c1 * d[i] + c2 * ((ri - s) / A.diag[i]);
+            const double zi = zin[i] + di;
+            d[i] = di;
+            zout[i] = zi;
+            acc += ri * zi;
+        }
+    }
+    if (last) {
+        const double sacc = block_sum(acc, red);
+        if (threadIdx.x == 0) part_rz[blockIdx.x] = sacc;
+    }
+}
+
 // update: sums the partials of p.q itself (P0); partials of r.z -> P1, r.r -> P2.  rz lives in scal[slot_old] /
 // scal[slot_new], exchanged by the host every iteration, so no kernel overwrites a scalar that another block of the same
 // launch may still read.
 __global__ void __launch_bounds__(256)
 k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__restrict__ p, const double *__restrict__ q,
                 const double *__restrict__ scal, int slot_old, const double *__restrict__ part_pap, int nb, double *part_rz,
-                double *part_rr)
+                double *part_rr, double zscale, double *dcheb)
 {
     __shared__ double red[4];
     __shared__ double bc;
@@ -2266,9 +2304,10 @@ k_coarse_update(CoarseDev A, double *x, double *r, double *z, const double *__re
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
         x[i] += alpha * p[i];
         const double ri = r[i] - alpha * q[i];
-        const double zi = ri / A.diag[i];
+        const double zi = dcheb ? zscale * (ri / A.diag[i]) : ri / A.diag[i];
         r[i] = ri;
         z[i] = zi;
+        if (dcheb) dcheb[i] = zi;
         rz += ri * zi;
         rr += ri * ri;
     }
@@ -2309,32 +2348,49 @@ void launch_coarse_scatter_sol(const Launch &L, const CoarseDev &A, int64_t nnod
                        A.n, x, u);
     check_launch();
 }
-void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z, double *p)
+void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z, double *p,
+                        double zscale, double *dcheb)
 {
     int nb = coarse_blocks(L, A.n);
-    hipLaunchKernelGGL(k_coarse_init, dim3(nb), dim3(256), 0, L.stream, A, b, x, r, z, p, L.partials, L.partials + 2048);
+    hipLaunchKernelGGL(k_coarse_init, dim3(nb), dim3(256), 0, L.stream, A, b, x, r, z, p, L.partials, L.partials + 2048, zscale, dcheb);
     check_launch();
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials, nb, L.scal, (int)S_C0);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 2048, nb, L.scal, (int)S_C2);
     HMG_HIP_CHECK(hipMemsetAsync(L.scal + S_DONE, 0, 3 * sizeof(double), L.stream));   // S_DONE, S_ITER, S_CRR
     check_launch();
 }
+
+void launch_coarse_cheb(const Launch &L, const CoarseDev &A, const double *r, const double *zin, double *zout, double *d, double c1,
+                        double c2, int last)
+{
+    const int nb = coarse_spmv_blocks(A.n);
+    hipLaunchKernelGGL(k_coarse_cheb, dim3(nb), dim3(256), 0, L.stream, A, r, zin, zout, d, c1, c2, L.scal, last, L.partials + 1024);
+    check_launch();
+}
+
+// scal[S_C0] = r.z from the partials the last Chebyshev step left (first iteration of a solve)
+void launch_coarse_rz_from_cheb(const Launch &L, const CoarseDev &A)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, L.stream, L.partials + 1024, coarse_spmv_blocks(A.n), L.scal, (int)S_C0);
+    check_launch();
+}
 // partial buffers of the PCG inside L.partials (>= 4096 doubles, nb <= 1024): P0 p.q, P1 r.z, P2 r.r
 void launch_coarse_direction(const Launch &L, const CoarseDev &A, double *p, double *q, const double *z, int slot_old, int slot_new,
-                             double rtol2, int mode, int count_it)
+                             double rtol2, int mode, int count_it, int rz_from_cheb)
 {
     const int nb = mode == 2 ? 1 : coarse_spmv_blocks(A.n);
     hipLaunchKernelGGL(k_coarse_direction, dim3(nb), dim3(256), 0, L.stream, A, p, q, z, L.scal, slot_old, slot_new,
-                       L.partials + 1024, L.partials + 2048, coarse_blocks(L, A.n), rtol2, mode, count_it, L.partials);
+                       L.partials + 1024, L.partials + 2048, coarse_blocks(L, A.n), rtol2, mode, count_it, L.partials,
+                       rz_from_cheb ? coarse_spmv_blocks(A.n) : coarse_blocks(L, A.n));
     check_launch();
 }
 
 void launch_coarse_update(const Launch &L, const CoarseDev &A, double *x, double *r, double *z, const double *p,
-                          const double *q, int slot_old)
+                          const double *q, int slot_old, double zscale, double *dcheb)
 {
     int nb = coarse_blocks(L, A.n);
     hipLaunchKernelGGL(k_coarse_update, dim3(nb), dim3(256), 0, L.stream, A, x, r, z, p, q, L.scal, slot_old, L.partials,
-                       coarse_spmv_blocks(A.n), L.partials + 1024, L.partials + 2048);
+                       coarse_spmv_blocks(A.n), L.partials + 1024, L.partials + 2048, zscale, dcheb);
     check_launch();
 }
 // r.r of the last update -> scal[S_TMP] (convergence check)

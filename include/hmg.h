@@ -78,8 +78,11 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * cells of the small levels; default 32, 0 = one workgroup per cell), "overlap_min_doubles" / "comm_rehearsal" (multi-GPU, below),
  * "vec_pool" (1 = default: hmg_vec_destroy keeps the block for the next
  * hmg_vec_create of the same size -- re-allocating freed device memory costs ~35 ms per GB here; 0 = free at once and
- * release what is held; hmg_ctx_destroy releases it too), "coarse_maxit", "coarse_check",
- * "time_apply"; "coarse_rtol" via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
+ * release what is held; hmg_ctx_destroy releases it too), "coarse_maxit", "coarse_check", "coarse_poly" (4 = default: the
+ * level-1 PCG is preconditioned by that many Chebyshev iterates of the Jacobi-scaled operator -- k - 1 sparse products without a
+ * reduction per outer iteration --; 1 = plain Jacobi), "weight_cache" / "apply_small" (1 = default: class weights of levels 2-6
+ * from the class-weight cache; levels 2-4 by the pipelined one-wave kernel, hmg_apply_small.hip),
+ * "time_apply"; "coarse_rtol" and "coarse_poly_ratio" (20: the interval [lmax / ratio, lmax]) via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
  * kernel for cells larger than the LDS, default 70). */
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
 int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value);

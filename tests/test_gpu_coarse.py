@@ -65,7 +65,7 @@ def test_budget_miss_is_reported_by_the_same_iteration_and_is_recoverable():
         base, cond, g, op, st = _problem(ctx, w, L, (1.0, 100.0))
         bl = hmg.BaseLevel(g)
         hmg.vcycle(g, bl, [op] * L, st, L, 3)                              # first solve: counted
-        assert bl.last_iterations() > 20
+        assert bl.last_iterations() > 10        # (plain Jacobi-PCG: 70; with the Chebyshev preconditioner of round 4: 19)
         hmg.vcycle(g, bl, [op] * L, st, L, 3)                              # budgeted, fine
         hmg.norm_unique(st[-1].r)
         ctx.set_option("coarse_rtol", 1e-40)
