@@ -65,7 +65,8 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * writes nothing -- its direction is formed in LDS for the apply and again on the fly by the one pass that does both pending
  * x-updates; x unchanged bit for bit), "apply_wave" (1 = default: cells of 969 nodes -- 3D level 5 -- are applied by one WAVE
  * per cell with the class weights taken from a cache that hmg_grid_set_operator fills, hmg_apply_wave.hip; 0 = the 256-thread
- * workgroup kernel; taken only where the mesh has at most 1024 distinct coefficient rows and |alpha| = 1), "prolong_in_image" (1 = default: on level 6 the folded prolongation stages the
+ * workgroup kernel; taken only where the mesh has at most 1024 distinct coefficient rows and |alpha| = 1; "wave_grid": its
+ * persistent waves per CU, default 16 = what the LDS holds, "wave_grid_total": the same as an absolute number -- tests), "prolong_in_image" (1 = default: on level 6 the folded prolongation stages the
  * coarse column at the even nodes of the LDS lattice image itself instead of in LDS of its own behind it, which would cost
  * the third resident workgroup; "prolong_gather", the option's round-2 name, is still accepted), "fold_restrict" (1 = default:
  * inside hmg_vcycle the local residual of levels 6 and 5 restricts itself in its kernel's epilogue and is not stored; the

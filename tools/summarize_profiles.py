@@ -72,6 +72,5 @@ if f_all:
     fp = os.path.join(src, "fingerprint.json")
     if os.path.exists(fp):
         rec.update(json.load(open(fp)))
-    rec["algorithmic_bytes_per_launch_then"] = None
     json.dump(rec, open(os.path.join(dst, "apply_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_summary.json")).read()[:3000])
