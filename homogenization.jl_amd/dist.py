@@ -402,7 +402,7 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
         base_level = api.BaseLevel(grid)
         dsig, dsig_prev = 0.0, 0.0
         for i in range(1, max_cycles + 1):
-            api.vcycle(grid, base_level, [op] * total_grids, states, total_grids, smoothing_steps)
+            api.vcycle_tolerant(grid, base_level, [op] * total_grids, states, total_grids, smoothing_steps)
             nint = grid.local_count_below(driver.find_elements_in_radius(cur, box_radius))
             area = api.integrate_area(top.x, grid, nint)
             if k == 0:

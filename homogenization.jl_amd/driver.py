@@ -248,7 +248,7 @@ def checkerboard_homogenization(n: int = 4, eltype=Tri64, refinements: int = 2, 
         base_level = api.BaseLevel(implicit)             # level-1 operator for the current lam / domain
         dsig, dsig_prev = 0.0, 0.0
         for i in range(1, max_cycles + 1):
-            api.vcycle(implicit, base_level, ops, states, total_grids, smoothing_steps)
+            api.vcycle_tolerant(implicit, base_level, ops, states, total_grids, smoothing_steps)
             nint = find_elements_in_radius(cur, box_radius)
             area = api.integrate_area(top.x, implicit, nint)
             if k == 0:

@@ -87,3 +87,25 @@ def test_budget_miss_is_reported_by_the_same_iteration_and_is_recoverable():
             hmg.vcycle(g, bl, [op] * L, st, L, 3)
     finally:
         ctx.close()
+
+
+def test_driver_loops_survive_a_budget_miss():
+    """vcycle_tolerant (what checkerboard_homogenization and its partitioned form call): a budgeted level-1 solve that runs out of
+    iterations makes that V-cycle a weaker iterate, not the end of the run -- False is returned, the budget is dropped, the next
+    cycle counts again and converges."""
+    ctx = hmg.Context(0)
+    try:
+        L, w = 3, 10
+        base, cond, g, op, st = _problem(ctx, w, L, (1.0, 100.0))
+        bl = hmg.BaseLevel(g)
+        assert hmg.vcycle_tolerant(g, bl, [op] * L, st, L, 3) is True        # counted
+        assert hmg.vcycle_tolerant(g, bl, [op] * L, st, L, 3) is True        # budgeted
+        ctx.set_option("coarse_rtol", 1e-40)
+        assert hmg.vcycle_tolerant(g, bl, [op] * L, st, L, 3) is False       # budgeted, cannot converge: reported, not raised
+        assert bl.misses() == 1
+        ctx.set_option("coarse_rtol", 1e-13)
+        r0 = hmg.norm_unique(st[-1].r)
+        assert hmg.vcycle_tolerant(g, bl, [op] * L, st, L, 3) is True
+        assert hmg.norm_unique(st[-1].r) < r0
+    finally:
+        ctx.close()
