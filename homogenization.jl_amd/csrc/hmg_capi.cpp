@@ -678,7 +678,14 @@ static void upload_levels(hmg_grid *g)
                         for (int t = ld.first; t < ld.second; ++t)
                             ldw.push_back((uint32_t)(T.meta[t] & 0xffffu) | ((uint32_t)t << 16));
                         auto cp = run(sg, sk[sl], sk[sl + 1]);
+                        const bool interior = si + 1 == seg.size();
                         for (int t = cp.first; t < cp.second; ++t) {
+                            // surface entries: i | j << 7 | k << 14 | cls << 21 (decode32w); cell interior (round 4): the lattice
+                            // position itself, L | j << 16 | k << 23 (decode_lattice: no tetrahedral-number arithmetic per node)
+                            if (interior)
+                                cpw.push_back((uint32_t)(T.meta[t] & 0xffffu) | (((uint32_t)T.slot_ijk[3 * t + 1] & 127u) << 16) |
+                                              (((uint32_t)T.slot_ijk[3 * t + 2] & 127u) << 23));
+                            else
                             cpw.push_back(((uint32_t)T.slot_ijk[3 * t] & 127u) | (((uint32_t)T.slot_ijk[3 * t + 1] & 127u) << 7) |
                                           (((uint32_t)T.slot_ijk[3 * t + 2] & 127u) << 14) | ((uint32_t)T.slot_cls[t] << 21));
                             cps.push_back((uint16_t)t);
@@ -718,6 +725,9 @@ static void upload_levels(hmg_grid *g)
                                 if ((i | j | k) & 1) continue;
                                 const int cs = cslot[cidx(i / 2, j / 2, k / 2)];
                                 if (cs < 0) throw std::runtime_error("slab restriction: even node without a coarse slot");
+                                if (si + 1 == seg.size())     // (cell interior: lattice-position form, as above)
+                                    rsw.push_back((uint32_t)(T.meta[t] & 0xffffu) | (((uint32_t)j & 127u) << 16) | (((uint32_t)k & 127u) << 23));
+                                else
                                 rsw.push_back(((uint32_t)i & 127u) | (((uint32_t)j & 127u) << 7) | (((uint32_t)k & 127u) << 14) |
                                               ((uint32_t)T.slot_cls[t] << 21));
                                 rss.push_back((uint16_t)cs);

@@ -915,8 +915,8 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
             t1 = (int)st.cp_slot[ib + v + 2 * NT];
             if (v < n_int) {
                 const double sv = sc ? sc[t] : 0.0;
-                int L, len, A, B, cls, k;
-                decode32w(pw, m, L, len, A, B, cls, k);
+                int L, len, A, B;
+                decode_lattice(pw, m, L, len, A, B);
                 double ctr;
                 double o = stencil_eval_v<DIM>(w0, xs + L, len, A, B, ctr);
                 if (!wdot) o = sv + o;

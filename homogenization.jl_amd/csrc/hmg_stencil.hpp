@@ -193,6 +193,19 @@ __device__ __forceinline__ void decode32w(uint32_t w, int m, int &L, int &len, i
     L = (full - rest) / 6 + j * (n + 1) - ((j * (j - 1)) >> 1) + i;
 }
 
+// Interior entries of the slab kernel's evaluation lists (round 4): the lattice position comes with the word, L | j << 16 | k << 23
+// -- decode32w spends a dozen integer instructions per node on it (two tetrahedral numbers, a division by 6).
+__device__ __forceinline__ void decode_lattice(uint32_t w, int m, int &L, int &len, int &A, int &B)
+{
+    L = (int)(w & 0xffffu);
+    const int j = (int)((w >> 16) & 127u), k = (int)((w >> 23) & 127u);
+    len = m + 1 - j - k;
+    const int n = m - k;
+    const int Tk = ((n + 1) * (n + 2)) >> 1;
+    A = Tk - j;
+    B = Tk + n + 2 - j;
+}
+
 // Stencil taps that leave the cell at a node in the interior of face F (F = 0: k = 0, 1: j = 0, 2: i = 0, 3: i+j+k = m;
 // tap numbering of stencil_eval_v): their class weights are zero, the host checks that against the class table.
 __host__ __device__ constexpr uint32_t face_tap_mask(int f)
