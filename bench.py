@@ -597,7 +597,8 @@ def main():
                          "levels": level_rows,
                          "levels_note": "outside the timed region: operator applies of every level between HIP events over 2 more "
                                         "V-cycles (level 5: one wave per cell, hmg::k_apply_wave), and each level's whole share of "
-                                        "a V-cycle from V-cycles started one level lower each time"},
+                                        "a V-cycle from V-cycles started one level lower each time (as the TOP level of such a V-cycle a lower level pays a full "
+                                        "residual and live smoother tails it does not pay inside a V-cycle started above: an upper bound)"},
             "build": fp,
         }
         out["ms_per_step_ranks"] = {"min": 1e3 * dt_rank_min / args.steps, "max": ms_step}
