@@ -77,6 +77,8 @@ def time_to_tolerance(ctx, hmg, driver, n, refinements, tolerance):
                             "level_vectors": tm["setup_alloc_s"], "x0_and_rhs": tm["setup_init_s"]},
             "solve_seconds": tm["solve_s"],
             "vcycles": tm["vcycles"], "outer_steps": tm["outer_steps"], "sigma": sigma,
+            "placement": "level vectors as allocated: the driver leaves hmg_level_tune_placement off (tuning costs more than 18 "
+                         "V-cycles gain) -- compare config.placement.ms_per_step_untuned, not ms_per_step",
             "base_mesh": f"{tm['width']}^3 unit cubes, {tm['cells']} cells",
             "level_vector_memory": "blocks the context kept when the bench's own level vectors were destroyed (option "
                                    "vec_pool; a fresh process allocates them in ~0.2 s, DESIGN.md section 4)"}

@@ -3179,9 +3179,28 @@ int hmg_level_tune_placement(hmg_grid *g, int level, int steps, hmg_vec **states
     };
     double t_first = 0.0, t_best = 0.0;
     try {
-        for (int e = 0; e < extra; ++e) blk.push_back(vec_alloc(c, bytes));
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
+        // Everything that can fail on ONE rank only (the spare blocks, the events) comes before the first collective, and on a
+        // partitioned grid the ranks agree on the outcome: run() below holds exchanges, and a rank that threw here alone would
+        // leave the others blocked in them.
+        std::string local_failure;
+        try {
+            for (int e = 0; e < extra; ++e) blk.push_back(vec_alloc(c, bytes));
+            HIPCHK(hipEventCreate(&e0));
+            HIPCHK(hipEventCreate(&e1));
+        } catch (const std::exception &ex) {
+            local_failure = ex.what();
+        }
+        if (has_exchange(g) && g->part && g->scalar_sum) {
+            double failed = local_failure.empty() ? 0.0 : 1.0;
+            double *d = c->L.scal + S_HOST;
+            HIPCHK(hipMemcpyAsync(d, &failed, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            scalar_sum(g, S_HOST, 1);
+            HIPCHK(hipMemcpyAsync(&failed, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (failed > 0.0 && local_failure.empty())
+                local_failure = "placement tuning: another rank could not set it up (nothing was changed on this rank)";
+        }
+        if (!local_failure.empty()) throw std::runtime_error(local_failure);
         const int nb = (int)blk.size();
         auto run = [&](const std::vector<int> &a) {
             assign(a);
