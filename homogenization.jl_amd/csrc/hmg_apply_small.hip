@@ -197,8 +197,8 @@ k_apply_small(LevelDev lv, const uint16_t *__restrict__ dmask, const int32_t *__
             }
         }
         if constexpr (FUSED) {
-            const double s_pap = wave_sum(pap), s_rr = wave_sum(rr);
-            if (lane == 0) {
+            const double s_pap = wave_sum63(pap), s_rr = wave_sum63(rr);
+            if (lane == 63) {
                 a.blockpart[2 * mycell] = s_pap;
                 a.blockpart[2 * mycell + 1] = s_rr;
             }

@@ -444,8 +444,8 @@ k_apply_wave(LevelDev lv, const uint16_t *__restrict__ dmask, const int32_t *__r
             }
         }
         if (FUSED && !RS) {
-            const double s_pap = wave_sum(pap), s_rr = wave_sum(rr);
-            if (lane == 0) {
+            const double s_pap = wave_sum63(pap), s_rr = wave_sum63(rr);
+            if (lane == 63) {
                 a.blockpart[2 * cell] = s_pap;
                 a.blockpart[2 * cell + 1] = s_rr;
             }

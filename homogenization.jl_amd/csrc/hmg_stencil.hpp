@@ -43,12 +43,35 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The same sum by data-parallel-primitive moves (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast 15 / 31 across the
+// rows): no LDS round trip per level -- wave_sum's __shfl_down is a ds_bpermute, six dependent ones per sum, which for the one-wave
+// kernels of the small levels was a quarter of a cell's life.  The total arrives in LANE 63.  (Another summation order than
+// wave_sum: used where only one kernel ever forms the sum.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    // lanes the move does not reach keep `old` = 0: +0.0 is added there
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum63(double v)
+{
+    v = dpp_add<0x111, 0xf>(v);     // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);     // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);     // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);     // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3  -> lane 63 holds the wave's sum
+    return v;
+}
+
 // all threads of the block call; result valid in thread 0. red: >= blockDim/64 doubles of LDS.
 __device__ __forceinline__ double block_sum(double v, double *red)
 {
-    v = wave_sum(v);
+    v = wave_sum63(v);                  // (round 4: cross-lane moves instead of six LDS round trips; the wave's sum is in lane 63)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) red[w] = v;
+    if (lane == 63) red[w] = v;
     __syncthreads();
     double s = 0.0;
     if (threadIdx.x == 0) {
