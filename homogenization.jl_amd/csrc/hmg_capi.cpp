@@ -153,6 +153,7 @@ struct hmg_ctx {
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
     bool lazy_post = true;      // ... and below the finest level its dead last step writes nothing: both x-updates in one pass
+    bool lazy_top = true;       // ... on the finest level its last step leaves both x-updates to the r-update (see smooth())
     bool zero_entry = true;        // V-cycle: a coarse level's zero initial guess is never materialised (see vcycle_down())
     bool fold_restrict = true;     // V-cycle: the restriction rides in the epilogue of the local residual, which is then not stored
     bool prolong_in_image = true;  // folded prolongation, level 6: the coarse column is staged at the even nodes of the lattice image
@@ -1370,9 +1371,18 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             // and one pass does both x-updates, p_i formed on the fly (32 B/DOF instead of 24): 48 instead of 64 B/DOF, x the
             // same to the last bit (round 4, option lazy_post)
             const bool lazy_x2 = dead && !defer_x && g->ctx->lazy_post && i > 0;
+            // the face part of Ap's interface sum rides in the r-update below, except on the last step of a smoother
+            // whose state is handed back (Ap must then hold what the reference leaves)
+            const bool ride = g->ctx->fold_faces && lv.dim == 3 && lv.nfi > 0 && !dead &&
+                              !(live_tail && !scratch_p && i == steps - 1);
+            // the last step of a smoother of which x and r are read and p is scratch (the finest level's post-smoother inside
+            // hmg_vcycle): the apply forms p_i in LDS only and writes Ap alone (24 instead of 48 B/DOF), the r-update carries both
+            // pending x-updates with p_i formed on the fly (48 B/DOF instead of 26 + the 24 of the final x-update): 72 instead of 98
+            // B/DOF for that step, x and r the same to the last bit (round 4, option lazy_top)
+            const bool lazy_top = live_tail && scratch_p && i == steps - 1 && i > 0 && ride && g->ctx->lazy_top;
             a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
-            a.xout = (i == 0 && swap_rp) || lazy_dead || lazy_x2 ? nullptr : p->d;   // (swap_rp: r_0 itself becomes p_0)
-            a.xacc = i == 0 || lazy_dead || lazy_x2 ? nullptr : x->d;     // x += alpha_{i-1} p_{i-1}
+            a.xout = (i == 0 && swap_rp) || lazy_dead || lazy_x2 || lazy_top ? nullptr : p->d;   // (swap_rp: r_0 itself becomes p_0)
+            a.xacc = i == 0 || lazy_dead || lazy_x2 || lazy_top ? nullptr : x->d;     // x += alpha_{i-1} p_{i-1}
             a.a_num = other;                                              // rs_{i-1} (after the swap below)
             a.a_den = S_PAP;                                              // p_{i-1}.Ap_{i-1}: still the old value here
             a.out = dead ? nullptr : Ap->d;
@@ -1400,10 +1410,13 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
                 d.b_den = other;
                 return d;
             }
-            // the face part of Ap's interface sum rides in the r-update below, except on the last step of a smoother
-            // whose state is handed back (Ap must then hold what the reference leaves)
-            const bool ride = g->ctx->fold_faces && lv.dim == 3 && lv.nfi > 0 && !dead &&
-                              !(live_tail && !scratch_p && i == steps - 1);
+            if (lazy_top) {
+                // (p.Ap of this step to its own slot: S_PAP keeps the previous step's for the first of the two x-updates)
+                apply_then_sum(g, lv, a, true, S_PAP2, -1, true, false);
+                launch_cg_rupdate_faces_x2(L, lv, g->md, r->d, r->d, Ap->d, n, cur, S_PAP2, other, x->d, p->d, other, S_PAP, cur, other);
+                scalar_sum(g, other, 1);
+                return none;
+            }
             apply_then_sum(g, lv, a, true, S_PAP, i == 0 ? cur : -1, true, !ride);
             const double *r_in = r->d;
             if (i == 0 && swap_rp) {
@@ -2324,6 +2337,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->lean_post = value != 0;
     else if (n == "lazy_post")
         ctx->lazy_post = value != 0;
+    else if (n == "lazy_top")
+        ctx->lazy_top = value != 0;
     else if (n == "prolong_in_image" || n == "prolong_gather")   // (prolong_gather: the option's name in round 2)
         ctx->prolong_in_image = value != 0;
     else if (n == "overlap_min_doubles")

@@ -219,6 +219,9 @@ void launch_cg_rupdate(const Launch &L, const double *r, double *rout, const dou
 // the same with the face part of q's interface sum taken on the fly (q unsummed on the shared faces)
 void launch_cg_rupdate_faces(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
                              const double *q, int64_t n, int s_num, int s_den, int s_out);
+void launch_cg_rupdate_faces_x2(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
+                                const double *q, int64_t n, int s_num, int s_den, int s_out, double *x, const double *p, int a_num,
+                                int a_den, int b_num, int b_den);
 // x += (scal[a_num]/scal[a_den]) p; with_p: p = r + (scal[s_num]/scal[s_den]) p
 void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
                          int s_num, int s_den, int with_p);

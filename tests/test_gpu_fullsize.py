@@ -181,7 +181,7 @@ def test_vcycle_contracts_full_size(prob):
     assert all(b < 0.7 * a for a, b in zip(norms, norms[1:])), norms
 
 
-EXACT = ("lean_post", "lazy_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict", "zero_entry", "cell_order")
+EXACT = ("lean_post", "lazy_post", "lazy_top", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict", "zero_entry", "cell_order")
 
 
 def test_exact_savings_leave_x_and_r_untouched_full_size(prob):

@@ -775,7 +775,7 @@ def test_handles_may_be_destroyed_in_any_order(oracle):
     c.close()                                     # last reference: grid and context go now
 
 
-EXACT_OPTIONS = ("lean_post", "lazy_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict",
+EXACT_OPTIONS = ("lean_post", "lazy_post", "lazy_top", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict",
                  "zero_entry", "cell_order")
 
 

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import homogenization_jl_amd as hmg
 from homogenization_jl_amd import driver
-OPTS = ("lean_post", "lazy_post", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict",
+OPTS = ("lean_post", "lazy_post", "lazy_top", "lazy_dead", "fold_x", "swap_rp", "fold_prolong", "prolong_in_image", "fold_faces", "fold_restrict",
         "zero_entry", "cell_order")
 dim, n, levels = 3, 4, int(sys.argv[1]) if len(sys.argv) > 1 else 5
 ctx = hmg.Context(0)
