@@ -208,6 +208,171 @@ k_apply_small(LevelDev lv, const uint16_t *__restrict__ dmask, const int32_t *__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Cells of at most 16 nodes (3D level 2: 10): FOUR cells per wave, one per row of 16 lanes.  With one cell per wave 10 of 64 lanes
+// worked and level 2 cost as much per cell as level 3; a wave's instruction stream is the same for one cell or four.
+//   * the lane's slot (its lattice position, class, tap offsets, restriction parents) is the same for every cell: decoded once;
+//   * class, Dirichlet mask and multiplicity word of the lane's cell are per-lane loads, fetched TWO quads ahead; the lane's class
+//     row (15 weights, straight from the class-weight cache into registers -- no LDS table) and its column values ONE quad ahead;
+//   * the per-cell sums are the first four stages of wave_sum63 (row_shr 1, 2, 4, 8: the row's sum in its lane 15) -- the bits
+//     k_apply_small's whole-wave sum gives for a cell that sits in row 0 with zeros behind it.
+// Same arithmetic per node as k_apply_small (the tests compare the two bit for bit).
+template <bool FUSED>
+__global__ void __launch_bounds__(64, 4)
+k_apply_pack(LevelDev lv, const uint16_t *__restrict__ dmask, const int32_t *__restrict__ cell_class, ApplyArgs a)
+{
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x, sub = lane >> 4, t = lane & 15, nf = lv.nf, m = lv.m;
+    const bool has = t < nf;
+    const int tc = has ? t : nf - 1;
+    const int imgp = lv.lds_g0 + nf + lv.lds_g1;
+    double *xs = smem + sub * imgp + lv.lds_g0;
+    const int64_t ld = lv.ld;
+    for (int q = lane; q < 4 * imgp; q += 64) smem[q] = 0.0;       // (guards stay zero; the images are rewritten per quad)
+
+    int L, len, A, B, cls;
+    decode32<3>(lv.pos32[tc], m, L, len, A, B, cls);
+    const int lp = (int)lv.lpos[tc];
+    const uint32_t par = FUSED && a.xcoarse ? lv.par32[tc] : 0u;
+    const int pa = (int)(par & 0xffffu), pb = (int)(par >> 16);
+    const int e = cls > 0 ? cls - 1 : 0;
+    const bool neg = a.alpha < 0.0;
+    double beta = 0.0, ax = 0.0, c2 = 0.0;
+    if constexpr (FUSED) {
+        beta = a.x2 ? a.scal[a.s_num] / a.scal[a.s_den] : 0.0;
+        ax = a.xacc || a.x3 ? a.scal[a.a_num] / a.scal[a.a_den] : 0.0;
+        c2 = a.x3 ? a.scal[a.c_num] / a.scal[a.c_den] : 0.0;
+    }
+    const bool xzero = FUSED && (a.flags & 128);
+    const int64_t G = gridDim.x, nquad = (a.nwork + 3) >> 2;
+
+    struct Meta {
+        int cell, wsel;
+        uint32_t dm, mw;
+        bool valid;
+    };
+    auto meta_of = [&](int64_t Q) {
+        Meta mt;
+        int64_t w = 4 * Q + sub;
+        mt.valid = w < a.nwork;
+        if (!mt.valid) w = a.nwork - 1;
+        mt.cell = a.cell_list ? a.cell_list[w] : (int)w;
+        mt.wsel = 2 * cell_class[mt.cell] + (neg ? 1 : 0);
+        mt.dm = (a.flags & 1) ? (uint32_t)dmask[mt.cell] : 0u;
+        mt.mw = FUSED && a.mult && cls > 0 ? (uint32_t)a.mult[(int64_t)mt.cell * 16 + e] : 1u;
+        return mt;
+    };
+    double2 pw2[8];
+    double pxv = 0.0, px2 = 0.0, pxa = 0.0, psv = 0.0, pca = 0.0, pcb = 0.0;
+    auto issue = [&](const Meta &mt) {
+        const double2 *wr = reinterpret_cast<const double2 *>(lv.wcache + (size_t)mt.wsel * WAVE_WSTRIDE + cls * WAVE_ROW);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pw2[q] = wr[q];
+        const int64_t o = (int64_t)mt.cell * ld + tc;
+        pxv = xzero ? 0.0 : a.x[o];
+        if (FUSED && a.x2) px2 = a.x2[o];
+        if (FUSED && a.xacc)
+            pxa = a.xacc[o];
+        else if (FUSED && a.x3)
+            pxa = a.x3[o];
+        if (a.src) psv = a.src[o];
+        if (FUSED && a.xcoarse) {
+            pca = a.xcoarse[(int64_t)mt.cell * a.ldc + pa];
+            pcb = a.xcoarse[(int64_t)mt.cell * a.ldc + pb];
+        }
+    };
+
+    int64_t Q = blockIdx.x;
+    if (Q >= nquad) return;
+    Meta cur = meta_of(Q);
+    issue(cur);
+    Meta nxt = meta_of(Q + G < nquad ? Q + G : Q);
+
+    for (;;) {
+        const Meta me = cur;
+        const int64_t o = (int64_t)me.cell * ld + t;
+        const bool live = has && me.valid;
+        double w[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            w[2 * q] = pw2[q].x;
+            w[2 * q + 1] = pw2[q].y;
+        }
+        double val = pxv, rr = 0.0, pap = 0.0;
+        if constexpr (FUSED) {
+            if (a.xcoarse) {        // interpolate_and_sum_to!: identity rows += 1.0 c[a], midpoints += 0.5 c[a], += 0.5 c[b]
+                const double ca = pca, cb = pcb;
+                const double vi = val + ca;
+                double vm = val;
+                vm += 0.5 * ca;
+                vm = vm + 0.5 * cb;
+                val = pa == pb ? vi : vm;
+            }
+            if (a.xacc && live) a.xacc[o] = axpy1(ax, px2, pxa);
+            if (a.x3) {
+                const double t1 = axpy1(ax, px2, val);
+                const double p2 = axpy1(beta, px2, pxa);
+                val = axpy1(c2, p2, t1);
+            } else if (a.x2)
+                val = axpy1(beta, px2, val);
+            if (a.xout && live) a.xout[o] = val;
+            if (!has) val = 0.0;
+            rr += val * val;
+        }
+        if (has) xs[lp] = val;
+        const double sv = a.src ? psv : 0.0;
+        // ---- the next quad's loads go out now; the words of the one after it are fetched here
+        const bool more = Q + G < nquad;
+        if (more) {
+            issue(nxt);
+            cur = nxt;
+            nxt = meta_of(Q + 2 * G < nquad ? Q + 2 * G : Q + G);
+        }
+        // ---- evaluation: the lane's node with its class row in registers (stencil_eval_c's order)
+        auto at = [&](int off) { return lds_ld(xs + max(L + off, 0)); };
+        const double ctr = lds_ld(xs + L);
+        double acc = w[0] * ctr;
+        acc += w[1] * lds_ld(xs + L + 1);
+        acc += w[2] * at(-1);
+        acc += w[3] * lds_ld(xs + L + len - 1);
+        acc += w[4] * at(-len);
+        acc += w[5] * lds_ld(xs + L + len);
+        acc += w[6] * at(-len - 1);
+        acc += w[7] * lds_ld(xs + L + A - len);
+        acc += w[8] * at(len + 1 - B);
+        acc += w[9] * lds_ld(xs + L + A - 1);
+        acc += w[10] * at(1 - B);
+        acc += w[11] * lds_ld(xs + L + A);
+        acc += w[12] * at(-B);
+        acc += w[13] * lds_ld(xs + L + A + 1 - len);
+        acc += w[14] * at(len - B);
+        double out = sv + acc;
+        if (cls > 0 && ((me.dm >> (cls - 1)) & 1u)) out = 0.0;
+        if (live && (!FUSED || a.out)) a.out[o] = out;
+        if constexpr (FUSED) {
+            if (has) {
+                const uint32_t mu = me.mw;
+                pap += (double)mu * (ctr * out);
+            }
+            pap = dpp_add<0x111, 0xf>(pap);
+            rr = dpp_add<0x111, 0xf>(rr);
+            pap = dpp_add<0x112, 0xf>(pap);
+            rr = dpp_add<0x112, 0xf>(rr);
+            pap = dpp_add<0x114, 0xf>(pap);
+            rr = dpp_add<0x114, 0xf>(rr);
+            pap = dpp_add<0x118, 0xf>(pap);
+            rr = dpp_add<0x118, 0xf>(rr);
+            if (t == 15 && me.valid) {
+                a.blockpart[2 * (int64_t)me.cell] = pap;
+                a.blockpart[2 * (int64_t)me.cell + 1] = rr;
+            }
+        }
+        if (!more) break;
+        Q += G;
+    }
+}
+
 bool apply_small_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused)
 {
     if (!L.apply_small || L.apply_threads != 0) return false;
@@ -235,6 +400,18 @@ void launch_apply_small(const Launch &L, const LevelDev &lv, const MeshDev &mesh
     if ((a.flags & 128) && !(fused && a.x3 && a.x2 && a.xout && !a.xcoarse))
         throw std::runtime_error("operator apply: the zero-input form exists for the residual with two pending x-updates only");
     a.nwork = nblocks;
+    if (lv.nf <= 16 && L.apply_pack && nblocks >= 4 && nblocks < (int64_t(1) << 31)) {
+        const int64_t nquad = (nblocks + 3) / 4;
+        const dim3 gq((unsigned)std::min<int64_t>(nquad, (int64_t)16 * L.num_cu)), bq(64);
+        const size_t ldsq = sizeof(double) * (size_t)(4 * (lv.lds_g0 + lv.nf + lv.lds_g1) + 64);
+        if (fused)
+            hipLaunchKernelGGL((k_apply_pack<true>), gq, bq, ldsq, L.stream, lv, mesh.dmask, mesh.cell_class, a);
+        else
+            hipLaunchKernelGGL((k_apply_pack<false>), gq, bq, ldsq, L.stream, lv, mesh.dmask, mesh.cell_class, a);
+        check_launch();
+        if (L.n_small_launches) *L.n_small_launches += 1;
+        return;
+    }
     const int64_t grid = std::min<int64_t>(nblocks, (int64_t)(lv.nf > 64 ? 16 : 20) * L.num_cu);
     const size_t lds = sizeof(double) * (size_t)(SW + lv.lds_g0 + lv.nf + lv.lds_g1 + 64);
     const dim3 g((unsigned)grid), b(64);

@@ -153,7 +153,7 @@ struct hmg_ctx {
     bool fold_faces = true;     // fused CG: the face part of Ap's interface sum rides in the r-update (all steps but a live last one)
     bool lean_post = true;      // V-cycle: the post-smoother's dead tail is dropped too (see vcycle_up())
     bool lazy_post = true;      // ... and below the finest level its dead last step writes nothing: both x-updates in one pass
-    bool lazy_top = true;       // ... on the finest level its last step leaves both x-updates to the r-update (see smooth())
+    int lazy_top = 2;           // ... on the finest level its last step leaves both x-updates to the r-update, 2: and the step before its own (see smooth())
     bool zero_entry = true;        // V-cycle: a coarse level's zero initial guess is never materialised (see vcycle_down())
     bool fold_restrict = true;     // V-cycle: the restriction rides in the epilogue of the local residual, which is then not stored
     bool prolong_in_image = true;  // folded prolongation, level 6: the coarse column is staged at the even nodes of the lattice image
@@ -301,6 +301,8 @@ struct hmg_grid {
     bool coarse_ready = false;
     DevBuf<int32_t> c_rowptr, c_colidx, c_interior;
     DevBuf<double> c_val, c_diag, c_b, c_x, c_r, c_z, c_p, c_q, c_u, c_z2, c_d;   // (c_z2, c_d: Chebyshev preconditioner)
+    DevBuf<double> top_spare;           // second direction vector of the finest level's post-smoother (smooth(), lazy_top = 2)
+    bool top_spare_refused = false;
     double c_lmax = 2.0;                         // Gershgorin bound of D^-1 A of the level-1 matrix
     int coarse_last_it = 0;
     int coarse_budget = 0;                       // iterations a solve enqueues blindly (0: not known yet)
@@ -1315,6 +1317,23 @@ struct DeferredX {
 // (src/multigrid.jl:68) is skipped and Ap stays unsummed on the faces (its face sums ride in the r-update).  For the
 // post-smoother of the finest level inside hmg_vcycle: the caller reads x and r (the driver's residual norm,
 // src/examples/homogenized_coefficients.jl:286), the next smoothing_steps! starts with p <- r and Ap <- 0.
+// the spare direction vector of smooth()'s three-update form (lazy_top = 2): allocated at first use, once per size
+bool top_spare_failed(hmg_grid *g, int64_t n)
+{
+    if (g->top_spare.n >= (size_t)n) return false;
+    if (g->top_spare_refused) return true;
+    double *q = nullptr;
+    if (hipMalloc((void **)&q, (size_t)n * sizeof(double)) != hipSuccess) {
+        (void)hipGetLastError();
+        g->top_spare_refused = true;
+        return true;
+    }
+    g->top_spare.release();
+    g->top_spare.p = q;
+    g->top_spare.n = (size_t)n;
+    return false;
+}
+
 DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
                  bool live_tail = true, bool defer_x = false, bool swap_rp = false, const hmg_vec *xcoarse = nullptr,
                  bool lazy = false, bool scratch_p = false, bool x_zero = false)
@@ -1359,6 +1378,7 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
         //            r -= alpha Ap;  r.r'
         // The x-update of step i rides with the fused apply of step i+1 (which reads p anyway); the last one
         // is done together with the reference's final p-update.
+        bool top3 = false;
         for (int i = 0; i < steps; ++i) {
             const bool dead = !live_tail && i == steps - 1;
             ApplyArgs a{};
@@ -1379,10 +1399,17 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             // hmg_vcycle): the apply forms p_i in LDS only and writes Ap alone (24 instead of 48 B/DOF), the r-update carries both
             // pending x-updates with p_i formed on the fly (48 B/DOF instead of 26 + the 24 of the final x-update): 72 instead of 98
             // B/DOF for that step, x and r the same to the last bit (round 4, option lazy_top)
-            const bool lazy_top = live_tail && scratch_p && i == steps - 1 && i > 0 && ride && g->ctx->lazy_top;
-            a.x2 = i == 0 ? nullptr : p->d;                               // p = r  /  p = r + beta p, beta = rs'/rs
-            a.xout = (i == 0 && swap_rp) || lazy_dead || lazy_x2 || lazy_top ? nullptr : p->d;   // (swap_rp: r_0 itself becomes p_0)
-            a.xacc = i == 0 || lazy_dead || lazy_x2 || lazy_top ? nullptr : x->d;     // x += alpha_{i-1} p_{i-1}
+            const bool top_form = live_tail && scratch_p && steps >= 2 && g->ctx->lazy_top > 0 && g->ctx->fold_faces && lv.dim == 3 && lv.nfi > 0;
+            const bool lazy_top = top_form && i == steps - 1;
+            // ... and the step before it (three steps or more) writes its direction into a spare vector next to the previous one
+            // instead of over it, so that ITS x-update can wait as well (the apply no longer reads and writes x: 32 instead of
+            // 48 B/DOF; the last pass reads one stream more: 56 instead of 48): 8 B/DOF less again (option lazy_top = 2, the
+            // default; the spare vector is allocated at first use -- if that fails the form above is taken)
+            if (top_form && steps >= 3 && g->ctx->lazy_top > 1 && i == steps - 2 && !top_spare_failed(g, n)) top3 = true;
+            const bool top3_here = top3 && i == steps - 2;
+            a.x2 = i == 0 ? nullptr : (top3 && lazy_top) ? g->top_spare.p : p->d;       // p = r  /  p = r + beta p, beta = rs'/rs
+            a.xout = (i == 0 && swap_rp) || lazy_dead || lazy_x2 || lazy_top ? nullptr : top3_here ? g->top_spare.p : p->d;   // (swap_rp: r_0 itself becomes p_0)
+            a.xacc = i == 0 || lazy_dead || lazy_x2 || lazy_top || top3_here ? nullptr : x->d;     // x += alpha_{i-1} p_{i-1}
             a.a_num = other;                                              // rs_{i-1} (after the swap below)
             a.a_den = S_PAP;                                              // p_{i-1}.Ap_{i-1}: still the old value here
             a.out = dead ? nullptr : Ap->d;
@@ -1410,10 +1437,29 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
                 d.b_den = other;
                 return d;
             }
+            if (top3_here) {
+                // slots: rs_{i-1} in `other`, p.Ap_{i-1} in S_PAP (both kept for the deferred x-update), rs_i in `cur`;
+                // this step's p.Ap goes to S_PAP2 and its r.r to S_RS3
+                apply_then_sum(g, lv, a, true, S_PAP2, -1, true, false);
+                launch_cg_rupdate_faces(L, lv, g->md, r->d, r->d, Ap->d, n, cur, S_PAP2, S_RS3);
+                scalar_sum(g, S_RS3, 1);
+                continue;
+            }
+            if (lazy_top && top3) {
+                // rs_{i-2} in `other`, rs_{i-1} in `cur`, rs_i in S_RS3;  p.Ap_{i-2} in S_PAP, p.Ap_{i-1} in S_PAP2;  p_{i-2} in p, p_{i-1} in the spare
+                a.s_num = S_RS3;
+                a.s_den = cur;
+                apply_then_sum(g, lv, a, true, S_PAP3, -1, true, false);
+                launch_cg_rupdate_faces_x(L, lv, g->md, r->d, r->d, Ap->d, n, S_RS3, S_PAP3, other, x->d, g->top_spare.p, cur, S_PAP2,
+                                          S_RS3, cur, p->d, other, S_PAP);
+                scalar_sum(g, other, 1);
+                return none;
+            }
             if (lazy_top) {
                 // (p.Ap of this step to its own slot: S_PAP keeps the previous step's for the first of the two x-updates)
                 apply_then_sum(g, lv, a, true, S_PAP2, -1, true, false);
-                launch_cg_rupdate_faces_x2(L, lv, g->md, r->d, r->d, Ap->d, n, cur, S_PAP2, other, x->d, p->d, other, S_PAP, cur, other);
+                launch_cg_rupdate_faces_x(L, lv, g->md, r->d, r->d, Ap->d, n, cur, S_PAP2, other, x->d, p->d, other, S_PAP, cur, other,
+                                          nullptr, 0, 0);
                 scalar_sum(g, other, 1);
                 return none;
             }
@@ -2237,6 +2283,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_wave = 1;    // level 5: one wave per cell where the class-weight cache exists (hmg_apply_wave.hip)
     c->L.wave_grid = 16 * (int64_t)c->L.num_cu;
     c->L.n_wave_launches = &c->wave_launches;
+    c->L.apply_pack = 1;    // level 2: four cells per wave
     c->L.apply_small = 1;   // levels 2-4: pipelined one-wave kernel (hmg_apply_small.hip)
     c->L.n_small_launches = &c->small_launches;
     c->L.apply_wg512 = 1;   // level 6: three 512-thread workgroups per CU (measured: V-cycle 149.5 -> 141 ms; 3 x 640 threads do not fit the wave slots: 174 ms)
@@ -2295,6 +2342,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_unblocked = value != 0;
     else if (n == "apply_wg512")
         ctx->L.apply_wg512 = value != 0;
+    else if (n == "apply_pack")            // 1 = default; 0: level 2 one cell per wave like levels 3-4 (A/B knob)
+        ctx->L.apply_pack = value != 0;
     else if (n == "apply_small")           // 1 = default; 0: levels 2-4 keep k_apply<3,64,*> (A/B knob)
         ctx->L.apply_small = value != 0;
     else if (n == "weight_cache")          // 1 = default; 0: level 6 combines its class weights per cell (A/B knob)
@@ -2338,7 +2387,7 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
     else if (n == "lazy_post")
         ctx->lazy_post = value != 0;
     else if (n == "lazy_top")
-        ctx->lazy_top = value != 0;
+        ctx->lazy_top = (int)value;
     else if (n == "prolong_in_image" || n == "prolong_gather")   // (prolong_gather: the option's name in round 2)
         ctx->prolong_in_image = value != 0;
     else if (n == "overlap_min_doubles")

@@ -140,9 +140,12 @@ struct CoarseDev {
 
 // scalar bank slots (device doubles)
 // (S_DONE / S_ITER / S_CRR: device-side state of the coarse PCG -- converged flag, iterations done, last r.r;
-//  slots 12..15: host sums of hmg_comm_sum_host)
+//  slots 12..15: host sums of hmg_comm_sum_host; S_RS3 / S_PAP3: the third pair of a smoother that defers three x-updates --
+//  the bank is 16 doubles by contract (hmg_ctx_set_scalar_bank), so they share S_C1, which the coarse PCG leaves alone, and S_TMP, a
+//  temporary of calls that cannot run inside a smoother)
 enum { S_RS = 0, S_PAP = 1, S_RS2 = 2, S_TMP = 3, S_C0 = 4, S_C1 = 5, S_C2 = 6, S_C3 = 7, S_PAP2 = 8, S_DONE = 9, S_ITER = 10,
-       S_CRR = 11, S_HOST = 12, S_COUNT = 16 };
+       S_CRR = 11, S_HOST = 12, S_COUNT = 16,
+       S_RS3 = S_C1, S_PAP3 = S_TMP };
 
 struct Launch {
     hipStream_t stream;
@@ -158,6 +161,7 @@ struct Launch {
                           // three workgroups (three columns in flight) per CU instead of two
     int cell_order;       // 1 (default): full-grid register-blocked apply launches walk the cells XCD by XCD (MeshDev::cell_perm)
     int weight_cache;     // 1 (default): level 6 takes its class weight rows from the class-weight cache where it exists
+    int apply_pack;       // 1 (default): cells of at most 16 nodes (3D level 2) four to a wave (k_apply_pack)
     int apply_small;      // 1 (default): levels 2-4 (3D, <= 192 nodes per cell) take the pipelined one-wave kernel where the cache exists
     int64_t *n_small_launches;
     int apply_wave;       // 1 (default): level 5 takes the one-wave-per-cell kernel where the class-weight cache exists
@@ -219,9 +223,9 @@ void launch_cg_rupdate(const Launch &L, const double *r, double *rout, const dou
 // the same with the face part of q's interface sum taken on the fly (q unsummed on the shared faces)
 void launch_cg_rupdate_faces(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
                              const double *q, int64_t n, int s_num, int s_den, int s_out);
-void launch_cg_rupdate_faces_x2(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
-                                const double *q, int64_t n, int s_num, int s_den, int s_out, double *x, const double *p, int a_num,
-                                int a_den, int b_num, int b_den);
+void launch_cg_rupdate_faces_x(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
+                               const double *q, int64_t n, int s_num, int s_den, int s_out, double *x, const double *p, int a_num,
+                               int a_den, int b_num, int b_den, const double *p0, int z_num, int z_den);
 // x += (scal[a_num]/scal[a_den]) p; with_p: p = r + (scal[s_num]/scal[s_den]) p
 void launch_cg_xp_update(const Launch &L, double *x, double *p, const double *r, int64_t n, int a_num, int a_den,
                          int s_num, int s_den, int with_p);

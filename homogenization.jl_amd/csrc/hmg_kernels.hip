@@ -1748,23 +1748,26 @@ k_cg_rupdate(const double *r, double *rout, const double *__restrict__ q, int64_
 // per-cell table fpart[4 * cell + face] = partner cell << 2 | partner face (-1: none) and added in ascending cell order --
 // the bits of the separate pass (k_iface_faces + k_cg_rupdate).  Saves that pass's read-modify-write of 28 % of q
 // (16 B per face DOF) for 8 B per face DOF more here.  q itself stays unsummed on the faces.
-// X2 (the last step of a smoother whose caller reads x and r only -- the finest level's post-smoother inside hmg_vcycle, option
+// XU > 0 (the last step of a smoother whose caller reads x and r only -- the finest level's post-smoother inside hmg_vcycle, option
 // lazy_top): the apply of that step formed p_i = r_i + beta p_{i-1} in LDS only and wrote neither p nor x; both pending x-updates
 // are done here, p_i formed again on the fly from the r this pass reads anyway:  x = (x + ax p) + alpha (r + beta p)  -- the
 // roundings of  x += alpha_{i-1} p_{i-1};  p_i = r_i + beta p_{i-1};  x += alpha_i p_i  one after the other (k_cg_x2_update).
-struct X2Slots {
-    int a_num, a_den, b_num, b_den;
+// XU == 2: a third pending update comes first, x += az p0 (the step before wrote its direction next to p0 instead of over it).
+struct XUSlots {
+    int a_num, a_den, b_num, b_den, z_num, z_den;
 };
-template <bool X2>
+template <int XU>
 __global__ void __launch_bounds__(SB)
 k_cg_rupdate_faces(const double *r, double *rout, const double *__restrict__ q, int64_t n, const double *__restrict__ scal,
                    int s_num, int s_den, double *partials, const int32_t *__restrict__ fpart, int ld, double inv_ld,
-                   int off_face, int off_int, int nfi, double *x, const double *__restrict__ p, X2Slots xs)
+                   int off_face, int off_int, int nfi, double *x, const double *__restrict__ p, const double *__restrict__ p0,
+                   XUSlots xs)
 {
     __shared__ double red[4];
     const double alpha = scal[s_num] / scal[s_den];
-    const double ax = X2 ? scal[xs.a_num] / scal[xs.a_den] : 0.0;
-    const double beta = X2 ? scal[xs.b_num] / scal[xs.b_den] : 0.0;
+    const double ax = XU ? scal[xs.a_num] / scal[xs.a_den] : 0.0;
+    const double beta = XU ? scal[xs.b_num] / scal[xs.b_den] : 0.0;
+    const double az = XU == 2 ? scal[xs.z_num] / scal[xs.z_den] : 0.0;
     auto xupd = [&](double xv, double pv, double rv) {
         const double t1 = axpy1(ax, pv, xv);
         const double p2 = axpy1(beta, pv, rv);
@@ -1794,9 +1797,14 @@ k_cg_rupdate_faces(const double *r, double *rout, const double *__restrict__ q, 
     if (i < (n >> 1)) {
         double2 rv = reinterpret_cast<const double2 *>(r)[i];
         const double2 qv = reinterpret_cast<const double2 *>(q)[i];
-        if (X2) {
+        if (XU) {
             double2 xv = reinterpret_cast<double2 *>(x)[i];
             const double2 pv = reinterpret_cast<const double2 *>(p)[i];
+            if (XU == 2) {
+                const double2 zv = reinterpret_cast<const double2 *>(p0)[i];
+                xv.x = axpy1(az, zv.x, xv.x);
+                xv.y = axpy1(az, zv.y, xv.y);
+            }
             xv.x = xupd(xv.x, pv.x, rv.x);
             xv.y = xupd(xv.y, pv.y, rv.y);
             reinterpret_cast<double2 *>(x)[i] = xv;
@@ -1808,7 +1816,7 @@ k_cg_rupdate_faces(const double *r, double *rout, const double *__restrict__ q, 
         acc += rv.y * rv.y;
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        if (X2) x[n - 1] = xupd(x[n - 1], p[n - 1], r[n - 1]);
+        if (XU) x[n - 1] = xupd(XU == 2 ? axpy1(az, p0[n - 1], x[n - 1]) : x[n - 1], p[n - 1], r[n - 1]);
         double rv = axpy1(-alpha, summed(n - 1, q[n - 1]), r[n - 1]);
         rout[n - 1] = rv;
         acc += rv * rv;
@@ -1985,23 +1993,29 @@ void launch_cg_rupdate_faces(const Launch &L, const LevelDev &lv, const MeshDev 
 {
     const int64_t nb = stream_blocks(n);
     check_grid(nb);
-    hipLaunchKernelGGL(k_cg_rupdate_faces<false>, dim3((unsigned)nb), dim3(SB), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den,
+    hipLaunchKernelGGL(k_cg_rupdate_faces<0>, dim3((unsigned)nb), dim3(SB), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den,
                        reduce_target(L, nb), mesh.face_partner, lv.ld, 1.0 / (double)lv.ld, lv.off_face, lv.off_int, lv.nfi,
-                       (double *)nullptr, (const double *)nullptr, X2Slots{0, 0, 0, 0});
+                       (double *)nullptr, (const double *)nullptr, (const double *)nullptr, XUSlots{0, 0, 0, 0, 0, 0});
     check_launch();
     reduce_finish(L, nb, s_out);
 }
 
-// ... with both pending x-updates of a lazy last step: x = (x + (a_num/a_den) p) + (s_num/s_den) (r + (b_num/b_den) p)
-void launch_cg_rupdate_faces_x2(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
-                                const double *q, int64_t n, int s_num, int s_den, int s_out, double *x, const double *p, int a_num,
-                                int a_den, int b_num, int b_den)
+// ... with the pending x-updates of a lazy last step: x = ((x [+ (z_num/z_den) p0]) + (a_num/a_den) p) + (s_num/s_den) (r + (b_num/b_den) p)
+void launch_cg_rupdate_faces_x(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const double *r, double *rout,
+                               const double *q, int64_t n, int s_num, int s_den, int s_out, double *x, const double *p, int a_num,
+                               int a_den, int b_num, int b_den, const double *p0, int z_num, int z_den)
 {
     const int64_t nb = stream_blocks(n);
     check_grid(nb);
-    hipLaunchKernelGGL(k_cg_rupdate_faces<true>, dim3((unsigned)nb), dim3(SB), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den,
-                       reduce_target(L, nb), mesh.face_partner, lv.ld, 1.0 / (double)lv.ld, lv.off_face, lv.off_int, lv.nfi, x, p,
-                       X2Slots{a_num, a_den, b_num, b_den});
+    const XUSlots xs{a_num, a_den, b_num, b_den, z_num, z_den};
+    if (p0)
+        hipLaunchKernelGGL(k_cg_rupdate_faces<2>, dim3((unsigned)nb), dim3(SB), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den,
+                           reduce_target(L, nb), mesh.face_partner, lv.ld, 1.0 / (double)lv.ld, lv.off_face, lv.off_int, lv.nfi, x, p,
+                           p0, xs);
+    else
+        hipLaunchKernelGGL(k_cg_rupdate_faces<1>, dim3((unsigned)nb), dim3(SB), 0, L.stream, r, rout, q, n, L.scal, s_num, s_den,
+                           reduce_target(L, nb), mesh.face_partner, lv.ld, 1.0 / (double)lv.ld, lv.off_face, lv.off_int, lv.nfi, x, p,
+                           p0, xs);
     check_launch();
     reduce_finish(L, nb, s_out);
 }

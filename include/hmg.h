@@ -63,8 +63,10 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * reference's own callers: the next smoothing_steps! overwrites them before reading, src/multigrid.jl:46-50;
  * 0 = they hold what the reference leaves), "lazy_post" (1 = default: below the top level the post-smoother's dead last step
  * writes nothing -- its direction is formed in LDS for the apply and again on the fly by the one pass that does both pending
- * x-updates; x unchanged bit for bit), "lazy_top" (1 = default: the same on the top level, where r is live as well -- the last
- * step's apply writes Ap alone and its r-update carries both x-updates; x and r unchanged bit for bit), "apply_wave" (1 = default: cells of 969 nodes -- 3D level 5 -- are applied by one WAVE
+ * x-updates; x unchanged bit for bit), "lazy_top" (the same on the top level, where r is live as well: 1 = the last
+ * step's apply writes Ap alone and its r-update carries both x-updates; 2 = default: with three steps or more the step before
+ * writes its direction into a spare vector of the top level's size, allocated at the first V-cycle, and leaves its x-update to
+ * that pass too; x and r unchanged bit for bit), "apply_wave" (1 = default: cells of 969 nodes -- 3D level 5 -- are applied by one WAVE
  * per cell with the class weights taken from a cache that hmg_grid_set_operator fills, hmg_apply_wave.hip; 0 = the 256-thread
  * workgroup kernel; taken only where the mesh has at most 1024 distinct coefficient rows and |alpha| = 1; "wave_grid": its
  * persistent waves per CU, default 16 = what the LDS holds, "wave_grid_total": the same as an absolute number -- tests), "prolong_in_image" (1 = default: on level 6 the folded prolongation stages the

@@ -197,6 +197,7 @@ def test_exact_savings_leave_x_and_r_untouched_full_size(prob):
     for on in (1, 0):
         for o in EXACT:
             ctx.set_option(o, on)
+        ctx.set_option("lazy_top", 2 * on)           # (2, the default: the three-update form with its spare vector)
         try:
             states = [hmg.LevelState(g, i + 1) for i in range(L)]
             top = states[-1]
@@ -210,6 +211,7 @@ def test_exact_savings_leave_x_and_r_untouched_full_size(prob):
         finally:
             for o in EXACT:
                 ctx.set_option(o, 1)
+            ctx.set_option("lazy_top", 2)
     a, b = res[0][-1], res[1][-1]
     assert hmg.dot(a.x, a.x) > 0.0
     hmg.axpy(-1.0, a.x, b.x)

@@ -19,5 +19,12 @@ t = [tag(r["Kernel_Name"]) for r in rows]
 n = 9
 for name, sl in (("last V-cycle", slice(-n, None)), ("previous    ", slice(-2 * n, -n))):
     print(name, " ".join("%s%.2f" % (a, b) for a, b in zip(t[sl], d[sl])), " sum %.2f  mean %.3f" % (sum(d[sl]), sum(d[sl]) / n))
+# every launch of the last V-cycle that takes more than a millisecond, in order (applies as above, ru = r-update, xp = x/p-update)
+allr = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+last = int(rows[-n]["Start_Timestamp"])
+short = lambda k: tag(k) if "k_apply<" in k else "ru" if "rupdate" in k else "xp" if "xp_update" in k else "x2" if "x2_update" in k else k.split("(")[0].split("::")[-1][:12]
+big = [(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6) for r in allr if int(r["Start_Timestamp"]) >= last]
+big = [(a, b) for a, b in big if b > 1.0]
+print("whole last V-cycle, launches > 1 ms:", " ".join("%s%.2f" % ab for ab in big), " sum %.2f" % sum(b for a, b in big))
 PY
 rm -rf $O/w1
