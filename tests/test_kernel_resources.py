@@ -72,3 +72,30 @@ def test_wave_kernel_fits_its_register_budget(tmp_path):
         assert name in found, f"instantiation {name} not compiled; have {sorted(found)}"
         assert found[name][0] <= vgprs, (name, found[name])
         assert found[name][1] <= scratch, (name, found[name])
+
+
+# hmg_apply_small.hip: k_apply_small<SPT, FUSED> (16 / 20 waves per CU: 128 / 102 VGPRs) and k_apply_pack<FUSED> (level 2, four
+# cells per wave, the lane's class row in registers: 16 waves per CU) -- no scratch in any of them
+SMALL_BUDGET = {
+    "12k_apply_packILb1E": (128, 0),
+    "12k_apply_packILb0E": (128, 0),
+    "13k_apply_smallILi1ELb1E": (102, 0),
+    "13k_apply_smallILi1ELb0E": (102, 0),
+    "13k_apply_smallILi3ELb1E": (128, 0),
+    "13k_apply_smallILi3ELb0E": (128, 0),
+}
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_small_level_kernels_fit_their_register_budget(tmp_path):
+    src = os.path.join(ROOT, "homogenization.jl_amd", "csrc", "hmg_apply_small.hip")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                          "-o", str(tmp_path / "s.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    found = {}
+    for m in re.finditer(r"Function Name: _ZN3hmg(\w+?)EEvNS_8LevelDev.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", out.stderr, re.S):
+        found[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    for name, (vgprs, scratch) in SMALL_BUDGET.items():
+        assert name in found, f"instantiation {name} not compiled; have {sorted(found)}"
+        assert found[name][0] <= vgprs, (name, found[name])
+        assert found[name][1] <= scratch, (name, found[name])
