@@ -1,5 +1,11 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-gcc -std=c99 -O0 -g -Iinclude examples/capi_vcycle.c -o /tmp/capi_vcycle -Lhomogenization.jl_amd -lhmg_hip -Wl,-rpath,$R/homogenization.jl_amd
-stdbuf -o0 -e0 /tmp/capi_vcycle 4 4 4; echo "rc=$?"
-timeout -k 10 200 /opt/rocm/bin/rocgdb -batch -ex run -ex bt --args /tmp/capi_vcycle 4 4 4 2>&1 | tail -40
-timeout -k 10 1000 python -m pytest tests -m gpu -q > gpurun_out/t10.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/t10.log
+bash tools/dev/bench_rehearsal.sh 2>&1 | grep -v "^   level\|placement" | cut -c1-400
+HMG_REHEARSE_WORLD=8 timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-time-to-tolerance --no-level-report > gpurun_out/bench_rank0of8.json 2> gpurun_out/bench_rank0of8.err; echo "rank0of8 rc=$?"
+HMG_SYNTHETIC_CUT=planes timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-time-to-tolerance --no-level-report > gpurun_out/bench_syncut.json 2> gpurun_out/bench_syncut.err; echo "syncut rc=$?"
+python3 - <<PY
+import json
+for f in ("bench_rank0of8", "bench_syncut"):
+    d = json.loads([x for x in open("gpurun_out/" + f + ".json").read().splitlines() if x.startswith("{")][-1])
+    print("%.2f %.3e %.3f %.3f %s %s" % (d["ms_per_step"], d["value"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d["config"]["residual_norm_after"], d["config"]["workload"]))
+    print("   comm", json.dumps(d.get("comm")))
+PY
