@@ -779,6 +779,40 @@ EXACT_OPTIONS = ("lean_post", "lazy_post", "lazy_top", "lazy_dead", "fold_x", "s
                  "zero_entry", "cell_order")
 
 
+@pytest.mark.parametrize("steps", [1, 2, 4, 5])
+def test_exact_savings_are_exact_for_other_step_counts(ctx, steps):
+    """The same with 1, 2, 4 and 5 smoothing steps on the finest level (the deferred x-updates of its post-smoother take another
+    form for each: none, two updates in the last r-update, three with the spare direction vector behind a regular step)."""
+    from homogenization_jl_amd import driver
+    levels = 4
+    base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, 4, levels, seed=12)
+    res = []
+    try:
+        for on in (1, 0, "lazy_top=1"):
+            for o in EXACT_OPTIONS:
+                ctx.set_option(o, 1 if on else 0)
+            ctx.set_option("lazy_top", {1: 2, 0: 0}.get(on, 1))
+            st = [hmg.LevelState(g, i + 1) for i in range(levels)]
+            st[-1].x.rand(3); st[-1].b.rand(4)
+            hmg.broadcast_interfaces(st[-1].x, g, levels)
+            hmg.apply_constraint(st[-1].x, levels, g)
+            bl = hmg.BaseLevel(g)
+            for _ in range(2):
+                hmg.vcycle(g, bl, [op] * levels, st, levels, steps)
+            res.append((st[-1].x.to_host(), st[-1].r.to_host()))
+            for s in st:
+                s.close()
+    finally:
+        for o in EXACT_OPTIONS:
+            ctx.set_option(o, 1)
+        ctx.set_option("lazy_top", 2)
+        g.close()
+    assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 0
+    for other in res[1:]:
+        np.testing.assert_array_equal(res[0][0], other[0])
+        np.testing.assert_array_equal(res[0][1], other[1])
+
+
 @pytest.mark.parametrize("dim,n,levels", [(3, 4, 5), (3, 2, 6), (2, 8, 5)])
 def test_exact_savings_are_exact(ctx, dim, n, levels):
     """Every saving hmg_vcycle takes that the reference's own control flow makes exact -- dead tails of both smoothers, r taken
