@@ -2242,6 +2242,42 @@ k_coarse_init(CoarseDev A, const double *__restrict__ b, double *x, double *r, d
     }
 }
 
+// Sparse product of the level-1 matrix, CR consecutive rows per group of 16 lanes: row r's entries go to the lanes as before (entry
+// rowptr[r] + lane, then every 16th: the Freudenthal lattice has <= 15 per row) and are folded in the same xor tree, so a row's sum
+// has the bits it always had -- but the (value, column) pairs and the gathers of CR rows are in flight together.  Round 4: with one
+// row per group a product was a chain of dependent round trips, 16 rounds per group at 64^3 cubes with four waves per SIMD: 21 us
+// for 49 MB.  Every lane of the group returns all CR sums.
+constexpr int CR = 4;
+__device__ __forceinline__ void coarse_rows_product(const CoarseDev &A, const double *__restrict__ z, int64_t i0, int sub, double (&s)[CR])
+{
+    int rp[CR + 1];
+#pragma unroll
+    for (int j = 0; j <= CR; ++j) rp[j] = A.rowptr[i0 + j < A.n ? i0 + j : A.n];
+    double v[CR], zz[CR];
+#pragma unroll
+    for (int j = 0; j < CR; ++j) {
+        const int k = rp[j] + sub;
+        const bool ok = k < rp[j + 1];
+        const int kc = ok ? k : 0;
+        v[j] = A.val[kc];
+        zz[j] = z[A.colidx[kc]];       // (not ok: entry 0, a valid address; its product is dropped)
+        if (!ok) v[j] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < CR; ++j) {
+        s[j] = 0.0;
+        s[j] += v[j] * zz[j];
+        for (int k = rp[j] + sub + 16; k < rp[j + 1]; k += 16) s[j] += A.val[k] * z[A.colidx[k]];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+#pragma unroll
+        for (int j = 0; j < CR; ++j) s[j] += __shfl_xor(s[j], o, 16);
+    }
+}
+
+static_assert(CR == 4, "the row epilogues pick one of four sums");
+
 // Two-launch form of one PCG iteration (round 3): `direction` + `update`.  With q = A p carried by its own recurrence,
 //   p' = z + beta p,   q' = A z + beta q      (A p' = A z + beta A p),
 // the sparse product reads z, which the previous update left complete, and never a neighbour's p -- so the p-update, the
@@ -2284,15 +2320,23 @@ k_coarse_direction(CoarseDev A, double *p, double *q, const double *__restrict__
     // per solve in round 2)
     const int sub = threadIdx.x & 15;
     double acc = 0.0;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < A.n; i += ((int64_t)gridDim.x * blockDim.x) >> 4) {
-        const int b = A.rowptr[i], e = A.rowptr[i + 1];
-        double s = 0.0;
-        for (int k = b + sub; k < e; k += 16) s += A.val[k] * z[A.colidx[k]];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-        if (sub == 0) {
-            const double pi = mode == 1 ? z[i] : z[i] + beta * p[i];
-            const double qi = mode == 1 ? s : s + beta * q[i];
+    for (int64_t i0 = CR * (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4); i0 < A.n; i0 += CR * (((int64_t)gridDim.x * blockDim.x) >> 4)) {
+        const int64_t i = i0 + sub;                     // lane j < CR finishes row i0 + j
+        const bool mine = sub < CR && i < A.n;
+        double zi = 0.0, pi0 = 0.0, qi0 = 0.0;
+        if (mine) {
+            zi = z[i];
+            if (mode != 1) {
+                pi0 = p[i];
+                qi0 = q[i];
+            }
+        }
+        double sr[CR];
+        coarse_rows_product(A, z, i0, sub, sr);
+        if (mine) {
+            const double s = sub == 0 ? sr[0] : sub == 1 ? sr[1] : sub == 2 ? sr[2] : sr[3];
+            const double pi = mode == 1 ? zi : zi + beta * pi0;
+            const double qi = mode == 1 ? s : s + beta * qi0;
             p[i] = pi;
             q[i] = qi;
             acc += pi * qi;
@@ -2317,16 +2361,22 @@ k_coarse_cheb(CoarseDev A, const double *__restrict__ r, const double *__restric
     if (scal[S_DONE] != 0.0 || !(scal[S_C2] > 0.0)) return;
     const int sub = threadIdx.x & 15;
     double acc = 0.0;
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < A.n; i += ((int64_t)gridDim.x * blockDim.x) >> 4) {
-        const int b = A.rowptr[i], e = A.rowptr[i + 1];
-        double s = 0.0;
-        for (int k = b + sub; k < e; k += 16) s += A.val[k] * zin[A.colidx[k]];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-        if (sub == 0) {
-            const double ri = r[i];
-            const double di = c1 * d[i] + c2 * ((ri - s) / A.diag[i]);
-            const double zi = zin[i] + di;
+    for (int64_t i0 = CR * (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4); i0 < A.n; i0 += CR * (((int64_t)gridDim.x * blockDim.x) >> 4)) {
+        const int64_t i = i0 + sub;                     // lane j < CR finishes row i0 + j
+        const bool mine = sub < CR && i < A.n;
+        double ri = 0.0, dold = 0.0, dg = 1.0, zold = 0.0;
+        if (mine) {
+            ri = r[i];
+            dold = d[i];
+            dg = A.diag[i];
+            zold = zin[i];
+        }
+        double sr[CR];
+        coarse_rows_product(A, zin, i0, sub, sr);
+        if (mine) {
+            const double s = sub == 0 ? sr[0] : sub == 1 ? sr[1] : sub == 2 ? sr[2] : sr[3];
+            const double di = c1 * dold + c2 * ((ri - s) / dg);
+            const double zi = zold + di;
             d[i] = di;
             zout[i] = zi;
             acc += ri * zi;

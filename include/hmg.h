@@ -84,8 +84,8 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * hmg_vec_create of the same size -- re-allocating freed device memory costs ~35 ms per GB here; 0 = free at once and
  * release what is held; hmg_ctx_destroy releases it too), "coarse_maxit", "coarse_check", "coarse_poly" (4 = default: the
  * level-1 PCG is preconditioned by that many Chebyshev iterates of the Jacobi-scaled operator -- k - 1 sparse products without a
- * reduction per outer iteration --; 1 = plain Jacobi), "weight_cache" / "apply_small" (1 = default: class weights of levels 2-6
- * from the class-weight cache; levels 2-4 by the pipelined one-wave kernel, hmg_apply_small.hip),
+ * reduction per outer iteration --; 1 = plain Jacobi), "weight_cache" / "apply_small" / "apply_pack" (1 = default: class weights of levels 2-6
+ * from the class-weight cache; levels 2-4 by the pipelined one-wave kernel, level 2 four cells to a wave, hmg_apply_small.hip),
  * "time_apply"; "coarse_rtol" and "coarse_poly_ratio" (20: the interval [lmax / ratio, lmax]) via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
  * kernel for cells larger than the LDS, default 70). */
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
@@ -95,8 +95,9 @@ int hmg_ctx_set_option_f64(hmg_ctx *ctx, const char *name, double value);
 int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, double *total_bytes);
 /* ... the same, only the launches of one level ("time_apply" = 1 times every level). */
 int hmg_ctx_apply_timing_level(hmg_ctx *ctx, int level, int64_t *launches, double *total_ms, double *total_bytes);
-/* diagnostic counters: "wave_launches" (launches of the one-wave-per-cell level-5 apply, hmg_apply_wave.hip),
-   "comm_calls", "comm_nranks" (ranks of the RCCL communicator made by hmg_comm_init, 0 without one); -1 for an unknown name.  No counterpart in the reference. */
+/* diagnostic counters: "wave_launches" (launches of the one-wave-per-cell level-5 apply, hmg_apply_wave.hip), "small_launches"
+   (levels 2-4, hmg_apply_small.hip), "comm_calls", "comm_nranks" (ranks of the RCCL communicator made by hmg_comm_init, 0 without
+   one); -1 for an unknown name.  No counterpart in the reference. */
 int64_t hmg_ctx_counter(hmg_ctx *ctx, const char *name);
 
 /* ---- grid: ImplicitFineGrid(base, levels)  (src/implicit_fine_grid.jl:13-18) ------------------ */

@@ -99,3 +99,22 @@ def test_small_level_kernels_fit_their_register_budget(tmp_path):
         assert name in found, f"instantiation {name} not compiled; have {sorted(found)}"
         assert found[name][0] <= vgprs, (name, found[name])
         assert found[name][1] <= scratch, (name, found[name])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_coarse_products_keep_their_row_sums_in_registers(tmp_path):
+    """k_coarse_cheb / k_coarse_direction hold the sums of the four rows a 16-lane group works on in a small array.  Picking one of
+    them with a loop over the array (instead of a chain of selects) made the backend move the array to LDS -- 8 KB per block, no
+    scratch, nothing in the register report -- and the level-1 solve of config 3 went from 0.95 to 3.8 ms (round 4).  LDS of these
+    kernels is the few doubles of their block reductions."""
+    src = os.path.join(ROOT, "homogenization.jl_amd", "csrc", "hmg_kernels.hip")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                          "-o", str(tmp_path / "k.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    seen = 0
+    for m in re.finditer(r"Function Name: _ZN3hmg\d+(k_coarse_cheb|k_coarse_direction)E.*?ScratchSize \[bytes/lane\]: (\d+).*?"
+                         r"LDS Size \[bytes/block\]: (\d+)", out.stderr, re.S):
+        seen += 1
+        assert int(m.group(2)) == 0, m.group(0)[-200:]
+        assert int(m.group(3)) <= 128, (m.group(1), m.group(3))
+    assert seen == 2
