@@ -582,7 +582,7 @@ def main():
             "data": f"synthetic (seeded checkerboard sigma in {{1,{args.sigma_high:g}}}, hashed x0, b = rhs_a.xi.grad(v), lambda=1)",
             "config": {"workload": workload, "cells": ne_total, "nf": nf, "levels": L,
                        "smoothing_steps": args.smoothing_steps, "smoothing_steps_coarse": 2,
-                       "coarse_solver": "device Jacobi-PCG rtol 1e-13",
+                       "coarse_solver": "device CG, Chebyshev(4)-of-Jacobi preconditioner, rtol 1e-13",
                        "coarse_iterations_last": base_level.last_iterations(),
                        "setup_seconds": setup_seconds, "placement": placement,
                        "residual_norm_after": rnorm},

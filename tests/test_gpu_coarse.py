@@ -1,6 +1,6 @@
 """
 Level-1 solve of the V-cycle (src/multigrid.jl:74-93; cholesky(...) \\ b of
-src/examples/homogenized_coefficients.jl:259-261 replaced by a device Jacobi-PCG): how a solve that is enqueued blindly --
+src/examples/homogenized_coefficients.jl:259-261 replaced by a device PCG -- Jacobi, since round 4 Chebyshev iterates of the Jacobi-scaled operator): how a solve that is enqueued blindly --
 no host round trip inside hmg_vcycle -- is policed.  The reference's direct solve cannot fail; here a failure must be
 loud, timely and recoverable.
 """
