@@ -28,8 +28,10 @@ static int cmp_i64(const void *a, const void *b)
 
 int main(int argc, char **argv)
 {
+    setvbuf(stdout, NULL, _IOLBF, 0); /* into a pipe as well: what was printed before a crash must not be lost with the buffer */
     const int n = argc > 1 ? atoi(argv[1]) : 4, levels = argc > 2 ? atoi(argv[2]) : 4;
     const int cycles = argc > 3 ? atoi(argv[3]) : 5;
+    printf("capi_vcycle: %d^3 unit cubes, %d levels, %d V-cycles\n", n, levels, cycles);
     const int k = n + 1;
     const int64_t nnodes = (int64_t)k * k * k, ncells = 6 * (int64_t)n * n * n;
     /* every unit cube split into 6 tetrahedra around the diagonal 0-6 (corner c = bit pattern of +1 per axis) */
