@@ -1277,6 +1277,23 @@ k_iface_csr(const int32_t *__restrict__ eptr, const int32_t *__restrict__ eent, 
         const int32_t *ptr = is_edge ? eptr : nptr, *ent = is_edge ? eent : nent;
         const int b = ptr[e], end = ptr[e + 1];
         double s = 0.0;
+        if (end - b <= U) {
+            // one batch (a shared edge has 4-6 copies): the entries stay in registers for the stores -- the general path below reads
+            // them a second time, one more dependent round trip per entity (round 4)
+            int32_t v[U];
+            double xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = b + u < end ? ent[b + u] : -1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[u] = v[u] >= 0 ? x[(int64_t)(v[u] >> 3) * ld + off + (v[u] & 7) * per + k] : 0.0;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (v[u] >= 0) s += xv[u];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (v[u] >= 0) x[(int64_t)(v[u] >> 3) * ld + off + (v[u] & 7) * per + k] = s;
+            continue;
+        }
         for (int q0 = b; q0 < end; q0 += U) {
             int32_t v[U];
             double xv[U];
