@@ -1,9 +1,2 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_dist.py -x -q 2>&1 | tail -2
-for rep in 1 2; do for lib in prev new; do
-  if [ $lib = prev ]; then export HMG_LIB_PATH=$R/homogenization.jl_amd/ab/libhmg_prev.so HMG_LIB_AB=1; else unset HMG_LIB_PATH HMG_LIB_AB; fi
-  timeout -k 10 300 python3 tools/level_bench.py 2>/dev/null | python3 -c "
-import sys, json
-r=[json.loads(l) for l in sys.stdin if l.startswith('{')]
-print('$lib', ' '.join('%d:%.3f' % (x['vcycle_from_level'], x['ms']) for x in r))"
-done; done
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/t13.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/t13.log
