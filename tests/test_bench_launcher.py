@@ -136,7 +136,10 @@ def test_supervisor_falls_back_when_the_first_attempt_hangs():
     res = _supervisors("hang_first", limit="4")
     assert [r[0] for r in res] == [0, 0], res
     rec = json.loads(res[0][1].strip().splitlines()[-1])
-    assert rec["launcher"]["attempt"] == 2 and "no result within" in rec["launcher"]["failed_attempts"][0]["why"]
+    # (both ranks hang: the supervisor whose clock runs out first writes the marker, the other one may see that marker before its own
+    #  limit -- either is the first attempt's failure as rank 0 records it)
+    why = rec["launcher"]["failed_attempts"][0]["why"]
+    assert rec["launcher"]["attempt"] == 2 and ("no result within" in why or "a peer's attempt failed" in why), why
 
 
 def test_supervisor_gives_up_after_both_forms():
