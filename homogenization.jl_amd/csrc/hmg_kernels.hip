@@ -394,6 +394,7 @@ k_apply(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict
                 const int t = tid + q * NT;
                 if (t < nf) {
                     const double v = axpy1(beta, x2v[q], xv[q]);
+                    if (LF == 2 && xoc) xoc[t] = v;      // (round 4: the step that writes its direction next to the old one, lazy_top = 2)
                     rr += v * v;
                     xs[lp[q]] = v;
                 }
@@ -1143,7 +1144,7 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
                         launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, F3, DIM == 3>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
                     else if (FUSED && !a.x2 && !a.xacc && !a.x3 && !a.xcoarse && !a.rcoarse)                 // CG step 0
                         launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, false, DIM == 3, F3 ? 1 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
-                    else if (FUSED && a.x2 && !a.xout && !a.xacc && !a.x3 && !a.xcoarse && !a.rcoarse)       // a dead step
+                    else if (FUSED && a.x2 && (!a.xout || a.xout != a.x2) && !a.xacc && !a.x3 && !a.xcoarse && !a.rcoarse)   // a dead step, or one that writes its direction elsewhere (no store may sit between the loads of a stream it aliases)
                         launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, false, DIM == 3, F3 ? 2 : 0>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
                     else
                         launch_apply_generic<DIM, 512, 13, FUSED, R6, false, false, false, DIM == 3>(L, lv, mesh, a, apply_lds_bytes_rb(lv));
