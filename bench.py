@@ -77,6 +77,7 @@ def time_to_tolerance(ctx, hmg, driver, n, refinements, tolerance):
                             "level_vectors": tm["setup_alloc_s"], "x0_and_rhs": tm["setup_init_s"]},
             "solve_seconds": tm["solve_s"],
             "vcycles": tm["vcycles"], "outer_steps": tm["outer_steps"], "sigma": sigma,
+            "inexact_vcycles": tm["inexact_vcycles"],      # level-1 solves that ran out of their iteration budget
             "placement": "level vectors as allocated: the driver leaves hmg_level_tune_placement off (tuning costs more than 18 "
                          "V-cycles gain) -- compare config.placement.ms_per_step_untuned, not ms_per_step",
             "base_mesh": f"{tm['width']}^3 unit cubes, {tm['cells']} cells",
@@ -236,8 +237,12 @@ def preflight(ctx, hmg, hdist, dist, world, rank, width=None, levels=5):
     A small brick (width^3 unit cubes per rank, level 5 on top) is solved twice by every rank -- partitioned over the N ranks
     with the exchange form of this run, and whole, unpartitioned, on the rank's own GPU -- from the same x0 and b (host twin of
     the device generator), two V-cycles each; the rank compares its columns.  Then the same partitioned V-cycles with the OTHER
-    exchange form (all-reduce over the global cut buffer <-> messages among the sharers): both forms add the ranks' partial sums
-    in ascending rank order, so x and r are expected to agree bit for bit.  Returns the record for the JSON line; `ok` = every
+    exchange form (all-reduce over the global cut buffer <-> messages among the sharers).  The sharers-only form adds the members'
+    partial sums in ascending rank order on every member (k_seg_sum); RCCL's all-reduce adds them in the order of its ring / tree.
+    An entity shared by TWO ranks gets the same bits from both (one addition, commutative); with three or more sharers (axis lines,
+    the centre node: 4 and 8 ranks) the forms agree to rounding only -- `other_form_bit_identical` is reported, never required
+    (profiles/r04_final_bench_lines.txt: false at 4 ranks; tests/test_dist_gloo.py pins the 2-rank equality and the 4-rank
+    tolerance).  Returns the record for the JSON line; `ok` = every
     rank within 1e-9 (x) / 1e-8 (r)."""
     import numpy as np
     import torch

@@ -7,13 +7,65 @@
  *       -Lhomogenization.jl_amd -lhmg_hip -Wl,-rpath,$PWD/homogenization.jl_amd
  *   ./capi_vcycle [n = 4] [levels = 4] [cycles = 5]
  */
+#define _XOPEN_SOURCE 700 /* sigaction, sigaltstack under -std=c99 */
+#include <execinfo.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
 
 #include "hmg.h"
 
+/* The program locates its own crashes: every ABI call leaves a breadcrumb on stderr (unbuffered) when HMG_EXAMPLE_TRACE is set or
+ * after a fatal signal, and SIGSEGV / SIGBUS / SIGFPE / SIGILL / SIGABRT print the faulting address, the last ABI call entered and
+ * a backtrace of the faulting thread (module + offset: resolve with `llvm-symbolizer -e <module> <offset>`), on a stack of their own. */
+static const char *volatile last_call = "(none yet)";
+static int trace_calls = 0;
+
+static void put(const char *s) { (void)!write(2, s, strlen(s)); }
+
+static void fatal_signal(int sig, siginfo_t *info, void *uctx)
+{
+    char buf[96];
+    void *frames[64];
+    (void)uctx;
+    snprintf(buf, sizeof buf, "\ncapi_vcycle: fatal signal %d, fault address %p\n", sig, info ? info->si_addr : (void *)0);
+    put(buf);
+    put("capi_vcycle: last ABI call entered: ");
+    put(last_call);
+    put("\ncapi_vcycle: backtrace of the faulting thread:\n");
+    backtrace_symbols_fd(frames, backtrace(frames, 64), 2);
+    signal(sig, SIG_DFL); /* die of the same signal: the exit status stays what it was */
+    raise(sig);
+}
+
+static void install_fatal_handlers(void)
+{
+    static char altstack[1 << 16];
+    stack_t ss;
+    struct sigaction sa;
+    const int sigs[] = {SIGSEGV, SIGBUS, SIGFPE, SIGILL, SIGABRT};
+    void *warm[1];
+    (void)backtrace(warm, 1); /* loads libgcc's unwinder now, not inside the handler */
+    ss.ss_sp = altstack;
+    ss.ss_size = sizeof altstack;
+    ss.ss_flags = 0;
+    sigaltstack(&ss, NULL);
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = fatal_signal;
+    sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    for (size_t i = 0; i < sizeof sigs / sizeof sigs[0]; ++i) sigaction(sigs[i], &sa, NULL);
+    trace_calls = getenv("HMG_EXAMPLE_TRACE") != NULL;
+}
+
 #define CHECK(call)                                                            \
     do {                                                                       \
+        last_call = #call;                                                     \
+        if (trace_calls) {                                                     \
+            put("-> " #call "\n");                                             \
+        }                                                                      \
         if ((call) != 0) {                                                     \
             fprintf(stderr, "%s failed: %s\n", #call, hmg_last_error());       \
             return 1;                                                          \
@@ -29,6 +81,11 @@ static int cmp_i64(const void *a, const void *b)
 int main(int argc, char **argv)
 {
     setvbuf(stdout, NULL, _IOLBF, 0); /* into a pipe as well: what was printed before a crash must not be lost with the buffer */
+    install_fatal_handlers();
+    if (argc > 1 && strcmp(argv[1], "--crash-selftest") == 0) { /* tests/test_c_abi_example.py: the evidence path itself */
+        last_call = "(crash self-test)";
+        raise(SIGSEGV);
+    }
     const int n = argc > 1 ? atoi(argv[1]) : 4, levels = argc > 2 ? atoi(argv[2]) : 4;
     const int cycles = argc > 3 ? atoi(argv[3]) : 5;
     printf("capi_vcycle: %d^3 unit cubes, %d levels, %d V-cycles\n", n, levels, cycles);
@@ -69,6 +126,9 @@ int main(int argc, char **argv)
     CHECK(hmg_grid_set_operator(grid, sigma, 1.0));
     CHECK(hmg_coarse_setup(grid));
 
+    /* the library's default V-cycle form keeps a sixth vector on the finest level: reserved here, explicitly, so that a device
+     * without room for it is an error at setup (hmg_grid_reserve_spare(grid, 0) would keep the reference's five vectors) */
+    CHECK(hmg_grid_reserve_spare(grid, 1));
     /* LevelState(x, b, r, p, Ap) of every level */
     hmg_vec **st = calloc((size_t)5 * levels, sizeof(hmg_vec *));
     for (int l = 0; l < levels; ++l)
@@ -93,10 +153,12 @@ int main(int argc, char **argv)
     for (int i = 0; i < 5 * levels; ++i) CHECK(hmg_vec_destroy(st[i]));
     CHECK(hmg_grid_destroy(grid));
     CHECK(hmg_ctx_destroy(ctx));
+    last_call = "(all handles destroyed; freeing host arrays)";
     free(st);
     free(sigma);
     free(cells);
     free(coords);
     printf(ok ? "residual decreased: ok\n" : "residual did NOT decrease\n");
+    last_call = "(main returned: exit handlers / static destructors of the loaded libraries)";
     return ok ? 0 : 2;
 }

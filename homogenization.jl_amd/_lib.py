@@ -44,6 +44,7 @@ SIGNATURES = {
     "hmg_grid_set_operator": (c_int, [vp, p_f64, c_f64]),
     "hmg_grid_set_lambda": (c_int, [vp, c_f64]),
     "hmg_grid_shrink": (c_int, [vp, c_i64, c_i64]),
+    "hmg_grid_reserve_spare": (c_int, [vp, c_int]),
     "hmg_grid_ncells": (c_i64, [vp]),
     "hmg_grid_nnodes": (c_i64, [vp]),
     "hmg_grid_nlevels": (c_int, [vp]),

@@ -201,6 +201,11 @@ class ImplicitFineGrid:
     def shrink(self, ncells_prefix, nnodes_prefix):
         L.check(self._lib.hmg_grid_shrink(self.h, ncells_prefix, nnodes_prefix))
 
+    def reserve_spare(self, enable=True):
+        """The sixth finest-level vector of the default V-cycle form (include/hmg.h: hmg_grid_reserve_spare): True reserves it now
+        and raises if the memory is not there, False releases it (the reference's five vectors per level)."""
+        L.check(self._lib.hmg_grid_reserve_spare(self.h, 1 if enable else 0))
+
     def coarse_setup(self):
         L.check(self._lib.hmg_coarse_setup(self.h))
 
@@ -482,8 +487,9 @@ def smoothing_steps(steps, implicit, ops, curr: LevelState, k: int):
 
 
 class BaseLevel:
-    """Coarse-level solver handle: the library's device-resident Jacobi-PCG on the assembled level-1
-    operator replaces `cholesky(assemble_checkerboard(...)[interior, interior])`."""
+    """Coarse-level solver handle: the library's device-resident CG on the assembled level-1 operator, preconditioned by
+    four Chebyshev iterates of the Jacobi-scaled operator (27 iterations at config 3), replaces
+    `cholesky(assemble_checkerboard(...)[interior, interior])`."""
 
     def __init__(self, implicit: ImplicitFineGrid):
         self.implicit = implicit

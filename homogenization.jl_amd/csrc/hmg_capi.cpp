@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -43,6 +44,41 @@ std::recursive_mutex &lifetime_mutex()
 }
 using LifetimeLock = std::lock_guard<std::recursive_mutex>;
 
+// Device / pinned allocations the library has made so far (hmg_ctx_counter "device_allocs"): after setup -- grid, operator, level-1
+// system, level vectors -- a V-cycle makes none (tests/test_gpu_parity.py::test_no_allocation_inside_a_vcycle).
+std::atomic<int64_t> &device_allocs()
+{
+    static std::atomic<int64_t> n{0};
+    return n;
+}
+
+// Host-only grids (hmg_grid_create with a NULL context: table queries, and the CPU sanitizer job of tests/test_sanitizers.py)
+// run every table builder as a device grid does; inside a DryUploads scope the uploads keep a running checksum of what WOULD have
+// gone to the device instead of touching the HIP runtime (hmg_grid_table_i32 "upload_hash": the same mesh must give the same
+// tables whatever the allocator hands out -- an uninitialised read shows up as a checksum that moves with ASan's malloc fill).
+struct DryUploads {
+    static DryUploads *&current()
+    {
+        static thread_local DryUploads *c = nullptr;
+        return c;
+    }
+    bool dry;
+    uint64_t *hash;
+    DryUploads *prev;
+    DryUploads(bool dry_, uint64_t *hash_) : dry(dry_), hash(hash_), prev(current()) { current() = this; }
+    ~DryUploads() { current() = prev; }
+    DryUploads(const DryUploads &) = delete;
+    DryUploads &operator=(const DryUploads &) = delete;
+    static bool active() { return current() && current()->dry; }
+    static void note(const void *data, size_t bytes)
+    {
+        uint64_t h = *current()->hash ^ (bytes * 0x9e3779b97f4a7c15ull);
+        const unsigned char *b = (const unsigned char *)data;
+        for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+        *current()->hash = h;
+    }
+};
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -61,16 +97,21 @@ struct DevBuf {
     {
         release();
         n = count;
-        if (!count) return;
+        if (!count || DryUploads::active()) return;
         if (hipMalloc((void **)&p, count * sizeof(T)) != hipSuccess) {
             (void)hipGetLastError();
             release_pooled_memory();             // blocks the contexts keep for reuse may be what is in the way
             HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
         }
+        device_allocs() += 1;
     }
     void upload(const std::vector<T> &h, hipStream_t s)
     {
         alloc(h.size());
+        if (DryUploads::active()) {
+            DryUploads::note(h.data(), h.size() * sizeof(T));
+            return;
+        }
         if (!h.empty()) {
             HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -177,6 +218,8 @@ struct hmg_ctx {
     int64_t comm_calls = 0, comm_doubles = 0;
     int64_t small_launches = 0;              // launches of the pipelined small-level apply
     int64_t wave_launches = 0;               // launches of the one-wave-per-cell apply (hmg_ctx_counter)
+    int64_t spare_bytes = 0;                 // spare direction vectors held by this context's grids (reserve_top_spare)
+    int last_top_form = 0;                   // form the last finest-level post-smoother inside hmg_vcycle took: 0 plain, 1 two-update, 2 three-update
     // Level-vector memory handed back by hmg_vec_destroy, kept for the next hmg_vec_create of the same size: on this
     // platform hipMalloc of memory the process has freed before costs ~35 ms per GB (tools/dev/alloc_probe.hip: 6 x 10 GB
     // 0.001 s fresh, 2.05 s after a hipFree), i.e. 1.9 s of the 71 GB a second driver call allocates.
@@ -229,6 +272,7 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
             c->vec_pool.pop_back();
             break;
         }
+    const bool pooled = p != nullptr;
     if (!p && hipMalloc(&p, bytes) != hipSuccess) {
         (void)hipGetLastError();
         release_pooled_memory();                 // pooled blocks of other sizes (any context's) may be what is in the way
@@ -237,6 +281,7 @@ double *vec_alloc(hmg_ctx *c, size_t bytes)
             throw std::runtime_error(std::string("hipMalloc of a level vector (") + std::to_string(bytes >> 20) +
                                      " MiB) failed: " + hipGetErrorString(e));
     }
+    if (!pooled) device_allocs() += 1;
     hipError_t e = hipMemsetAsync(p, 0, bytes, c->stream);
     if (e != hipSuccess) {
         (void)hipFree(p);
@@ -343,6 +388,8 @@ struct hmg_grid {
     int64_t ex_cap = 0;
     DevBuf<double> own_exbuf;                    // hmg_grid_use_comm: library-owned exchange buffer
 
+    uint64_t upload_hash = 1469598103934665603ull;   // host-only grids: checksum of every table a device grid would upload (DryUploads)
+
     const MeshTables &cur() const { return shrunk ? mesh : mesh_full; }
 };
 
@@ -418,8 +465,8 @@ void upload_mesh(hmg_grid *g)
     d0.dim = M.dim;
     d0.ncells = M.ncells;
     d0.nnodes = M.nnodes;
-    if (!g->ctx) return;   // host-only grid (table queries, no device)
-    hipStream_t s = g->ctx->stream;
+    DryUploads dry_scope(!g->ctx, &g->upload_hash);   // host-only grid: the tables are built and checksummed, nothing is uploaded
+    hipStream_t s = g->ctx ? g->ctx->stream : nullptr;
     g->d_cells.upload(M.cells, s);
     g->d_face_pairs.upload(M.face_pairs, s);
     {
@@ -436,7 +483,12 @@ void upload_mesh(hmg_grid *g)
     g->d_node_ptr.upload(M.node_ptr, s);
     g->d_node_ent.upload(M.node_ent, s);
     g->d_node_first.upload(M.node_first, s);
-    g->d_dmask.upload(M.dmask, s);
+    {   // the class-weight-cache kernels read the masks of two neighbouring cells as ONE 32-bit word (HMG_KP(uint32_t, dmask)[cell >> 1]
+        // in hmg_kernels.hip / hmg_apply_wave.hip / hmg_apply_small.hip): an even number of entries, whatever the cell count
+        std::vector<uint16_t> dm(M.dmask);
+        if (dm.size() & 1) dm.push_back((uint16_t)0);
+        g->d_dmask.upload(dm, s);
+    }
     g->d_dupmask.upload(M.dupmask, s);
     g->d_mult.upload(M.mult, s);
 #ifdef HMG_PHASE_TIMING
@@ -509,6 +561,7 @@ void upload_mesh(hmg_grid *g)
 }  // namespace
 static void upload_levels(hmg_grid *g)
 {
+    DryUploads dry_scope(!g->ctx, &g->upload_hash);
     hipStream_t s = g->ctx ? g->ctx->stream : nullptr;
     g->ld.resize(g->nlevels);
     for (int l = 0; l < g->nlevels; ++l) {
@@ -517,7 +570,7 @@ static void upload_levels(hmg_grid *g)
         LevelBufs &B = *g->lb.back();
         std::vector<uint32_t> B_blk_word_host;     // host copies for the tables of k_apply_wave (below)
         std::vector<uint16_t> B_blk_slot_host, wave_cl_host;
-        if (g->ctx) {
+        {
             B.meta.upload(T.meta, s);
             {
                 std::vector<uint16_t> lp(T.meta.size());
@@ -1007,8 +1060,9 @@ void build_cell_classes(hmg_grid *g)
         cls[(size_t)c] = it->second;
     }
     g->nclasses = (int)ids.size();
-    g->d_cell_class.upload(cls, g->ctx->stream);
-    g->d_coef_rep.upload(rep, g->ctx->stream);
+    hipStream_t s = g->ctx ? g->ctx->stream : nullptr;
+    g->d_cell_class.upload(cls, s);
+    g->d_coef_rep.upload(rep, s);
     g->md.cell_class = g->d_cell_class.p;
     g->md.nclasses = g->nclasses;
 }
@@ -1022,7 +1076,10 @@ void ensure_weight_cache(hmg_grid *g)
         LevelDev &D = g->ld[l];
         if (D.level < 2 || D.ncls != 15) continue;           // (every 3D level an operator is applied on: k_apply<.., WC>, k_apply_wave)
         LevelBufs &B = *g->lb[l];
-        B.wcache.alloc((size_t)g->nclasses * 2 * WAVE_WSTRIDE);
+        if (B.wcache.n != (size_t)g->nclasses * 2 * WAVE_WSTRIDE) {
+            HIPCHK(hipStreamSynchronize(g->ctx->stream));   // (kernels that read the old cache)
+            B.wcache.alloc((size_t)g->nclasses * 2 * WAVE_WSTRIDE);
+        }
         launch_weight_cache(g->ctx->L, D, g->d_coef_rep.p, g->nclasses, g->lambda, B.wcache.p);
         D.wcache = B.wcache.p;
     }
@@ -1043,10 +1100,11 @@ void upload_operator(hmg_grid *g)
     }
     build_cell_coefficients(M, g->sigma.data(), g->coef);
     g->coarse_ready = false;
-    if (!g->ctx) return;
-    g->d_coef.upload(g->coef, g->ctx->stream);
+    DryUploads dry_scope(!g->ctx, &g->upload_hash);
+    g->d_coef.upload(g->coef, g->ctx ? g->ctx->stream : nullptr);
     g->md.coef = g->d_coef.p;
     build_cell_classes(g);
+    if (g->ctx) ensure_weight_cache(g);          // formed here, not in front of the first apply: a V-cycle allocates nothing
 }
 
 void exchange_cut(hmg_grid *g, const LevelDev &lv, double *x);   // defined below
@@ -1317,21 +1375,54 @@ struct DeferredX {
 // (src/multigrid.jl:68) is skipped and Ap stays unsummed on the faces (its face sums ride in the r-update).  For the
 // post-smoother of the finest level inside hmg_vcycle: the caller reads x and r (the driver's residual norm,
 // src/examples/homogenized_coefficients.jl:286), the next smoothing_steps! starts with p <- r and Ap <- 0.
-// the spare direction vector of smooth()'s three-update form (lazy_top = 2): allocated at first use, once per size
-bool top_spare_failed(hmg_grid *g, int64_t n)
+// The spare direction vector of smooth()'s three-update form (lazy_top = 2) is SETUP: reserved when the first vector of the finest
+// level is created or wrapped (or by hmg_grid_reserve_spare), never inside a smoother.  Without it (reservation refused for lack of
+// memory, option lazy_top < 2 at that time, hmg_grid_reserve_spare(grid, 0)) smooth() takes the two-update form -- which form the
+// last finest-level post-smoother took is reported by hmg_ctx_counter "lazy_top_form", the bytes held by "spare_bytes".
+bool reserve_top_spare(hmg_grid *g, bool must)
 {
-    if (g->top_spare.n >= (size_t)n) return false;
-    if (g->top_spare_refused) return true;
+    hmg_ctx *c = g->ctx;
+    const LevelDev &lv = g->ld[(size_t)g->nlevels - 1];
+    const size_t n = (size_t)lv.ld * (size_t)g->mesh_full.ncells;
+    if (g->top_spare.n >= n && n > 0) return true;
+    if (g->top_spare_refused && !must) return false;
+    HIPCHK(hipSetDevice(c->device));
     double *q = nullptr;
-    if (hipMalloc((void **)&q, (size_t)n * sizeof(double)) != hipSuccess) {
+    if (hipMalloc((void **)&q, n * sizeof(double)) != hipSuccess) {
         (void)hipGetLastError();
-        g->top_spare_refused = true;
-        return true;
+        release_pooled_memory();
+        if (hipMalloc((void **)&q, n * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            g->top_spare_refused = true;
+            if (must)
+                throw std::runtime_error("the spare direction vector of the finest level (" + std::to_string((n * sizeof(double)) >> 20) +
+                                         " MiB, option lazy_top = 2) does not fit the device memory; V-cycles take the two-update form");
+            return false;
+        }
     }
+    device_allocs() += 1;
+    c->spare_bytes -= (int64_t)(g->top_spare.n * sizeof(double));
     g->top_spare.release();
     g->top_spare.p = q;
-    g->top_spare.n = (size_t)n;
-    return false;
+    g->top_spare.n = n;
+    g->top_spare_refused = false;
+    c->spare_bytes += (int64_t)(n * sizeof(double));
+    return true;
+}
+
+void release_top_spare(hmg_grid *g)
+{
+    if (g->ctx) {
+        if (g->top_spare.p) (void)hipStreamSynchronize(g->ctx->stream);
+        g->ctx->spare_bytes -= (int64_t)(g->top_spare.n * sizeof(double));
+    }
+    g->top_spare.release();
+}
+
+// the three-update form applies to: 3D grids whose finest level has face interiors (smooth(): top_form)
+bool wants_top_spare(const hmg_grid *g, int level)
+{
+    return g->ctx && g->ctx->lazy_top > 1 && level == g->nlevels && g->dim == 3 && g->ld[(size_t)level - 1].nfi > 0;
 }
 
 DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_vec *r, hmg_vec *p, hmg_vec *Ap,
@@ -1405,7 +1496,8 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             // instead of over it, so that ITS x-update can wait as well (the apply no longer reads and writes x: 32 instead of
             // 48 B/DOF; the last pass reads one stream more: 56 instead of 48): 8 B/DOF less again (option lazy_top = 2, the
             // default; the spare vector is allocated at first use -- if that fails the form above is taken)
-            if (top_form && steps >= 3 && g->ctx->lazy_top > 1 && i == steps - 2 && !top_spare_failed(g, n)) top3 = true;
+            if (top_form && steps >= 3 && g->ctx->lazy_top > 1 && i == steps - 2 && g->top_spare.n >= (size_t)n) top3 = true;
+            if (top_form && i == steps - 1) g->ctx->last_top_form = top3 ? 2 : 1;
             const bool top3_here = top3 && i == steps - 2;
             a.x2 = i == 0 ? nullptr : (top3 && lazy_top) ? g->top_spare.p : p->d;       // p = r  /  p = r + beta p, beta = rs'/rs
             a.xout = (i == 0 && swap_rp) || lazy_dead || lazy_x2 || lazy_top ? nullptr : top3_here ? g->top_spare.p : p->d;   // (swap_rp: r_0 itself becomes p_0)
@@ -1525,8 +1617,8 @@ void coarse_setup(hmg_grid *g)
     need(g->has_op, "hmg_grid_set_operator must be called first");
     const MeshTables &M = g->part ? g->part->global : g->cur();
     assemble_coarse_matrix(M, g->part ? g->sigma_global.data() : g->sigma.data(), g->lambda, g->cm);
-    if (!g->ctx) return;
-    hipStream_t s = g->ctx->stream;
+    DryUploads dry_scope(!g->ctx, &g->upload_hash);
+    hipStream_t s = g->ctx ? g->ctx->stream : nullptr;
     g->c_rowptr.upload(g->cm.rowptr, s);
     g->c_colidx.upload(g->cm.colidx, s);
     g->c_val.upload(g->cm.val, s);
@@ -1559,6 +1651,12 @@ void coarse_setup(hmg_grid *g)
     g->cd.val = g->c_val.p;
     g->cd.diag = g->c_diag.p;
     g->cd.interior = g->c_interior.p;
+    if (!g->ctx) return;                           // (host-only grid: the matrix is assembled and checksummed, there is nothing to solve on)
+    if (!g->probe->h) {
+        HIPCHK(hipHostMalloc((void **)&g->probe->h, 4 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&g->probe->ev, hipEventDisableTiming));
+        device_allocs() += 1;
+    }
     g->coarse_ready = true;
     // New matrix: the first solve counts its iterations again.  A probe the previous matrix's last solve left behind is
     // waited for and dropped here -- judged by coarse_pcg() it would put the old matrix's count back into the budget
@@ -1599,10 +1697,7 @@ void coarse_pcg(hmg_grid *g)
     }
     coarse_probe_wait(g);                          // the previous solve's verdict (throws if it did not converge)
     CoarseProbe &pr = *g->probe;
-    if (!pr.h) {
-        HIPCHK(hipHostMalloc((void **)&pr.h, 4 * sizeof(double), hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&pr.ev, hipEventDisableTiming));
-    }
+    need(pr.h != nullptr, "level-1 solve without a level-1 system (coarse_setup)");
     const double rtol2 = c->coarse_rtol * c->coarse_rtol;
     // Polynomial preconditioner (round 4): z = p_{k-1}(D^-1 A) D^-1 r by k - 1 Chebyshev steps behind the init / update kernel (each
     // one sparse product, no reduction) -- an outer iteration is k + 1 launches for k products instead of two launches and two
@@ -1901,6 +1996,7 @@ CutLevel &cut_level(hmg_grid *g, const LevelDev &lv)
     CutLevel &C = *g->cutlv[lv.level - 1];
     if (C.ready) return C;
     const int64_t per[3] = {lv.nfi, lv.nei, 1};
+    DryUploads dry_scope(!g->ctx, &g->upload_hash);
     hipStream_t st = g->ctx ? g->ctx->stream : nullptr;
     std::vector<int64_t> pos;
     if (!g->sharers) {
@@ -1911,7 +2007,7 @@ CutLevel &cut_level(hmg_grid *g, const LevelDev &lv)
         for (int k = 0; k < 3; ++k) {
             pos.resize(g->cut[k].gid.size());
             for (size_t e = 0; e < pos.size(); ++e) pos[e] = off + g->cut[k].gid[e] * per[k];
-            if (g->ctx) C.pos[k].upload(pos, st);
+            C.pos[k].upload(pos, st);
             off += g->cut[k].nglobal * per[k];
         }
         C.ndoubles = off;
@@ -1929,7 +2025,7 @@ CutLevel &cut_level(hmg_grid *g, const LevelDev &lv)
                 const int64_t kbase = k == 0 ? 0 : k == 1 ? S.count[0] * per[0] : S.count[0] * per[0] + S.count[1] * per[1];
                 pos[e] = soff[(size_t)g->cut[k].seg[e]] + kbase + g->cut[k].sidx[e] * per[k];
             }
-            if (g->ctx) C.pos[k].upload(pos, st);
+            C.pos[k].upload(pos, st);
         }
         C.ndoubles = soff[nseg];
         // messages (one per segment and peer) and the summation plan: every member adds the members' partial segments in
@@ -1963,7 +2059,7 @@ CutLevel &cut_level(hmg_grid *g, const LevelDev &lv)
         C.nstage = stage;
         for (size_t q = 0; q < nseg; ++q) plan[4 + 4 * q] += (int64_t)(1 + 4 * nseg);    // absolute offsets of the member tables
         plan.insert(plan.end(), mtab.begin(), mtab.end());
-        if (g->ctx) C.plan.upload(plan, st);
+        C.plan.upload(plan, st);
     }
     C.ready = true;
     return C;
@@ -2225,6 +2321,7 @@ static void grid_unref(hmg_grid *grid)
         (void)hipStreamSynchronize(c->stream);
     }
     probe_unlist(grid);
+    release_top_spare(grid);
     if (grid->probe && grid->probe->h) (void)hipHostFree(grid->probe->h);
     if (grid->probe && grid->probe->ev) (void)hipEventDestroy(grid->probe->ev);
     delete grid;
@@ -2318,6 +2415,9 @@ int64_t hmg_ctx_counter(hmg_ctx *ctx, const char *name)
     if (n == "wave_launches") return ctx->wave_launches;
     if (n == "small_launches") return ctx->small_launches;
     if (n == "comm_calls") return ctx->comm_calls;
+    if (n == "device_allocs") return device_allocs().load();
+    if (n == "spare_bytes") return ctx->spare_bytes;
+    if (n == "lazy_top_form") return ctx->last_top_form;
     if (n == "comm_nranks") return ctx->comm ? ctx->comm_nranks : 0;     // as the RCCL communicator was created; 0: none
     return -1;
 }
@@ -2515,12 +2615,13 @@ static void finish_partition(hmg_grid *g)
     for (int k = 0; k < 3; ++k)
         set_cut_kind(g, k, P.nglobal[k], (int64_t)P.gid[k].size(), P.gid[k].data(), P.cell_lid[k].data(), P.seg_of[k].data(),
                      P.seg_idx[k].data());
-    if (!g->ctx) return;
-    g->d_nodes_g.upload(P.nodes_g, g->ctx->stream);
-    g->d_owned.upload(P.owned_node, g->ctx->stream);
+    DryUploads dry_scope(!g->ctx, &g->upload_hash);
+    hipStream_t s = g->ctx ? g->ctx->stream : nullptr;
+    g->d_nodes_g.upload(P.nodes_g, s);
+    g->d_owned.upload(P.owned_node, s);
     std::vector<int32_t> cg(M.cells.size());
     for (size_t q = 0; q < cg.size(); ++q) cg[q] = P.nodes_g[M.cells[q]];
-    g->d_cells_gnode.upload(cg, g->ctx->stream);
+    g->d_cells_gnode.upload(cg, s);
 }
 
 static int create_partition(hmg_ctx *ctx, int dim, int nlevels, int64_t nnodes, const double *coords, int64_t ncells,
@@ -2602,6 +2703,21 @@ int hmg_grid_set_lambda(hmg_grid *g, double lambda)
     need(g != nullptr, "null grid");
     g->lambda = lambda;
     g->coarse_ready = false;
+    if (g->ctx && g->has_op) ensure_weight_cache(g);
+    HMG_END
+}
+
+int hmg_grid_reserve_spare(hmg_grid *g, int enable)
+{
+    HMG_TRY
+    need(g != nullptr, "null grid");
+    need(g->ctx != nullptr, "this grid was created without a device context (host tables only)");
+    if (enable) {
+        (void)reserve_top_spare(g, true);
+    } else {
+        release_top_spare(g);
+        g->top_spare_refused = true;             // ... and the first vector of the finest level does not bring it back
+    }
     HMG_END
 }
 
@@ -2659,6 +2775,9 @@ int hmg_grid_table_i32(const hmg_grid *g, int level, const char *which, int32_t 
     if (w == "dmask" || w == "dupmask") {
         const auto &m = w == "dmask" ? g->cur().dmask : g->cur().dupmask;
         tmp.assign(m.begin(), m.end());
+        src = &tmp;
+    } else if (w == "upload_hash") {   // host-only grids: checksum of every table a device grid would have uploaded so far (two halves)
+        tmp = {(int32_t)(uint32_t)(g->upload_hash & 0xffffffffu), (int32_t)(uint32_t)(g->upload_hash >> 32)};
         src = &tmp;
     } else if (w == "face_pairs") {
         src = &g->cur().face_pairs;
@@ -2820,6 +2939,7 @@ int hmg_vec_create(hmg_grid *g, int level, hmg_vec **out)
     ensure_reduce_scratch(g->ctx, (int64_t)lv.ld * g->md.ncells);
     v->d = vec_alloc(g->ctx, bytes);
     v->bytes = bytes;
+    if (wants_top_spare(g, level)) (void)reserve_top_spare(g, false);
     {
         LifetimeLock lock(lifetime_mutex());
         g->refs += 1;
@@ -2839,6 +2959,7 @@ int hmg_vec_wrap(hmg_grid *g, int level, void *device_ptr, hmg_vec **out)
     v->own = false;
     v->alloc_cells = g->md.ncells;
     v->d = (double *)device_ptr;
+    if (wants_top_spare(g, level)) (void)reserve_top_spare(g, false);
     {
         LifetimeLock lock(lifetime_mutex());
         g->refs += 1;
@@ -3420,9 +3541,9 @@ static void set_cut_kind(hmg_grid *g, int k, int64_t nglobal, int64_t n, const i
     }
     g->cutlv.clear();                            // buffer layouts are rebuilt at the next exchange
     g->cut_agreed_ready = false;                 // ... and the ranks agree on the size of the new cut at the next apply
-    if (!g->ctx) return;
-    c.cell_lid.upload(hc, g->ctx->stream);
-    c.first.upload(first, g->ctx->stream);
+    DryUploads dry_scope(!g->ctx, &g->upload_hash);
+    c.cell_lid.upload(hc, g->ctx ? g->ctx->stream : nullptr);
+    c.first.upload(first, g->ctx ? g->ctx->stream : nullptr);
 }
 
 int hmg_grid_set_cut(hmg_grid *g, int64_t ngf, int64_t nge, int64_t ngn, int64_t nlf, const int64_t *face_gid,

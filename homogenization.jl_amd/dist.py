@@ -12,6 +12,7 @@ scalars and the gather of level-1 nodal values for the replicated coarse solve (
 from __future__ import annotations
 
 import ctypes
+import warnings
 import weakref
 
 import numpy as np
@@ -356,12 +357,13 @@ def partitioned_checkerboard(ctx, width: int, levels: int, world: int, rank: int
 def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, rank: int, refinements: int = 2,
                                             smoothing_steps: int = 3, tolerance: float = 1e-4, xi=None, seed: int = 0,
                                             values=(1.0, 9.0), sigma_grid=None, x0=None, max_cycles: int = 1000,
-                                            group=None, log=None, backend=None):
+                                            group=None, log=None, backend=None, stats: dict | None = None):
     """driver.checkerboard_homogenization over `world` ranks (one GPU each): the base mesh is split into blocks about
     the origin (halves / quadrants / octants for 2, 4, 8 ranks), so that the centred sub-domains the outer loop
     shrinks to stay balanced.  Every rank runs the same host loop; the per-cycle integrals are local sums
     added over the ranks, everything else goes through the partitioned V-cycle.  Returns (sigma, history) like the
-    single-GPU driver, identical on every rank."""
+    single-GPU driver, identical on every rank.  `stats` (a dict) receives "inexact_vcycles": V-cycles whose budgeted level-1 solve
+    missed coarse_rtol (every rank sees the same replicated solve, hence the same count)."""
     dim = api._dim_of(eltype)
     # the blocks are halves per axis about the origin: 1, 2, 4 (and 8 in 3D) ranks.  Checked on every rank before any
     # collective, so that an unsupported size fails everywhere instead of hanging the ranks that do own cells
@@ -398,11 +400,16 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
     rank_sum = ex.rank_sum
     cur = base
     history = []
+    inexact = 0
     for k in range(n + 1):
         base_level = api.BaseLevel(grid)
         dsig, dsig_prev = 0.0, 0.0
         for i in range(1, max_cycles + 1):
-            api.vcycle_tolerant(grid, base_level, [op] * total_grids, states, total_grids, smoothing_steps)
+            if not api.vcycle_tolerant(grid, base_level, [op] * total_grids, states, total_grids, smoothing_steps):
+                inexact += 1                             # (as in driver.checkerboard_homogenization: counted and said)
+                if rank == 0:
+                    warnings.warn(f"partitioned_checkerboard_homogenization: V-cycle {i} of outer step {k} used an inexact "
+                                  f"level-1 solve ({inexact} so far)")
             nint = grid.local_count_below(driver.find_elements_in_radius(cur, box_radius))
             area = api.integrate_area(top.x, grid, nint)
             if k == 0:
@@ -435,4 +442,6 @@ def partitioned_checkerboard_homogenization(ctx, n: int, eltype, world: int, ran
         v_prev.copyto(top.x)
         op.lam = lam
         api.next_rhs(top.b, top.x, grid)
+    if stats is not None:
+        stats["inexact_vcycles"] = inexact
     return sigma, history

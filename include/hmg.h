@@ -65,7 +65,8 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * writes nothing -- its direction is formed in LDS for the apply and again on the fly by the one pass that does both pending
  * x-updates; x unchanged bit for bit), "lazy_top" (the same on the top level, where r is live as well: 1 = the last
  * step's apply writes Ap alone and its r-update carries both x-updates; 2 = default: with three steps or more the step before
- * writes its direction into a spare vector of the top level's size, allocated at the first V-cycle, and leaves its x-update to
+ * writes its direction into a spare vector of the top level's size -- reserved when the first vector of the finest level is
+ * created or wrapped, or by hmg_grid_reserve_spare; never inside a V-cycle -- and leaves its x-update to
  * that pass too; x and r unchanged bit for bit), "apply_wave" (1 = default: cells of 969 nodes -- 3D level 5 -- are applied by one WAVE
  * per cell with the class weights taken from a cache that hmg_grid_set_operator fills, hmg_apply_wave.hip; 0 = the 256-thread
  * workgroup kernel; taken only where the mesh has at most 1024 distinct coefficient rows and |alpha| = 1; "wave_grid": its
@@ -97,7 +98,11 @@ int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, doub
 int hmg_ctx_apply_timing_level(hmg_ctx *ctx, int level, int64_t *launches, double *total_ms, double *total_bytes);
 /* diagnostic counters: "wave_launches" (launches of the one-wave-per-cell level-5 apply, hmg_apply_wave.hip), "small_launches"
    (levels 2-4, hmg_apply_small.hip), "comm_calls", "comm_nranks" (ranks of the RCCL communicator made by hmg_comm_init, 0 without
-   one); -1 for an unknown name.  No counterpart in the reference. */
+   one), "device_allocs" (device / pinned allocations the library has made in this process: constant across hmg_vcycle once the
+   grid, its operator, its level-1 system and the level vectors exist), "spare_bytes" (spare direction vectors held by this
+   context's grids, see hmg_grid_reserve_spare), "lazy_top_form" (the form the last finest-level post-smoother inside hmg_vcycle
+   took: 2 = three-update form with the spare vector, 1 = two-update form, 0 = plain); -1 for an unknown name.  No counterpart in
+   the reference. */
 int64_t hmg_ctx_counter(hmg_ctx *ctx, const char *name);
 
 /* ---- grid: ImplicitFineGrid(base, levels)  (src/implicit_fine_grid.jl:13-18) ------------------ */
@@ -114,6 +119,13 @@ int hmg_grid_set_lambda(hmg_grid *grid, double lambda);
  * the prefix lengths are GLOBAL; every rank keeps its cells below the prefix (a prefix of its own columns) and the
  * cut entities, masks and ownership are re-derived. */
 int hmg_grid_shrink(hmg_grid *grid, int64_t ncells_prefix, int64_t nnodes_prefix);
+/* The reference's LevelState holds five vectors per level (src/multigrid.jl:18-25).  With option "lazy_top" = 2 (the default) the
+ * finest level's post-smoother inside hmg_vcycle uses a SIXTH vector of that level's size (+20 % on the finest level's footprint)
+ * to save 8 B/DOF of traffic per V-cycle.  It belongs to the grid and is setup, not hot-path, memory: reserved automatically when
+ * the first vector of the finest level is created or wrapped (if that allocation fails, V-cycles silently-but-reportedly take the
+ * two-update form: hmg_ctx_counter "lazy_top_form" / "spare_bytes"), or explicitly here: enable = 1 reserves it now and FAILS if
+ * the memory is not there; enable = 0 releases it and keeps it released (the five-vector footprint of the reference). */
+int hmg_grid_reserve_spare(hmg_grid *grid, int enable);
 int64_t hmg_grid_ncells(const hmg_grid *grid);
 int64_t hmg_grid_nnodes(const hmg_grid *grid);
 int hmg_grid_nlevels(const hmg_grid *grid);

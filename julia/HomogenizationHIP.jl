@@ -121,6 +121,12 @@ bind!(g::HipGrid, ops::AbstractVector, k::Int) = bind!(g, ops[k])
 shrink!(g::HipGrid, ncells_prefix::Integer, nnodes_prefix::Integer) =
     check(ccall((:hmg_grid_shrink, LIB), Cint, (Ptr{Cvoid}, Int64, Int64), g.h, ncells_prefix, nnodes_prefix))
 
+# The sixth finest-level vector of the library's default V-cycle form (include/hmg.h: hmg_grid_reserve_spare).  true: reserve it now
+# (an error if the device memory is not there); false: release it and keep the reference's five-vector footprint.  Without a call
+# it is reserved when the first HipMatrix of the finest level is created.
+reserve_spare!(g::HipGrid, enable::Bool = true) =
+    check(ccall((:hmg_grid_reserve_spare, LIB), Cint, (Ptr{Cvoid}, Cint), g.h, enable ? 1 : 0))
+
 # ---- HipMatrix: the AbstractMatrix a LevelState is parametrised with (api.DeviceMatrix) ------------------------------
 mutable struct HipMatrix <: AbstractMatrix{Float64}
     h::Ptr{Cvoid}

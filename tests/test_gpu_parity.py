@@ -834,8 +834,15 @@ def test_exact_savings_are_exact(ctx, dim, n, levels):
             hmg.broadcast_interfaces(st[-1].x, g, levels)
             hmg.apply_constraint(st[-1].x, levels, g)
             bl = hmg.BaseLevel(g)
+            allocs = ctx.counter("device_allocs")
             for _ in range(3):
                 hmg.vcycle(g, bl, [op] * levels, st, levels, 3)
+            # setup is over once grid, operator, level-1 system and level vectors exist: not even the FIRST V-cycle allocates
+            # (the spare direction vector of lazy_top = 2 was reserved with the finest level's first vector)
+            assert ctx.counter("device_allocs") == allocs
+            if dim == 3:
+                assert ctx.counter("lazy_top_form") == {1: 2, 0: 0}.get(on, 1)
+                assert ctx.counter("spare_bytes") >= 8 * g.ld(levels) * g.ncells()
             res.append((st[-1].x.to_host(), st[-1].r.to_host(), hmg.norm_unique(st[-1].r)))
             for s in st:
                 s.close()
@@ -848,3 +855,37 @@ def test_exact_savings_are_exact(ctx, dim, n, levels):
         np.testing.assert_array_equal(res[0][0], other[0])
         np.testing.assert_array_equal(res[0][1], other[1])
         assert res[0][2] == other[2] and np.isfinite(res[0][2])
+
+
+def test_spare_vector_is_setup_memory_with_a_reported_state(ctx):
+    """hmg_grid_reserve_spare (round 5): the sixth finest-level vector of the three-update form is reserved at setup, released on
+    request -- V-cycles then take the two-update form and say so -- and x, r are the same bits either way."""
+    from homogenization_jl_amd import driver
+    levels = 4
+    base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, 4, levels, seed=5)
+    res = []
+    try:
+        held = ctx.counter("spare_bytes")              # (other grids of this context that are still alive)
+        for spare in (True, False, True):
+            g.reserve_spare(spare)
+            assert ctx.counter("spare_bytes") - held == (8 * g.ld(levels) * g.ncells() if spare else 0)
+            st = [hmg.LevelState(g, i + 1) for i in range(levels)]
+            assert ctx.counter("spare_bytes") - held == (8 * g.ld(levels) * g.ncells() if spare else 0)   # (released stays released)
+            st[-1].x.rand(3); st[-1].b.rand(4)
+            hmg.broadcast_interfaces(st[-1].x, g, levels)
+            hmg.apply_constraint(st[-1].x, levels, g)
+            bl = hmg.BaseLevel(g)
+            allocs = ctx.counter("device_allocs")
+            for _ in range(2):
+                hmg.vcycle(g, bl, [op] * levels, st, levels, 3)
+            assert ctx.counter("device_allocs") == allocs
+            assert ctx.counter("lazy_top_form") == (2 if spare else 1)
+            res.append((st[-1].x.to_host(), st[-1].r.to_host()))
+            for s_ in st:
+                s_.close()
+    finally:
+        g.close()
+    assert ctx.counter("spare_bytes") == held             # the grid took its spare vector with it
+    for other in res[1:]:
+        np.testing.assert_array_equal(res[0][0], other[0])
+        np.testing.assert_array_equal(res[0][1], other[1])

@@ -1,0 +1,66 @@
+"""
+CPU sanitizer job for the host side of libhmg_hip.so (round 5; VERDICT r4 "next" 1).
+
+The HOST code of every source file is instrumented (`make asan tsan` in csrc: AddressSanitizer + UBSan + LeakSanitizer, and
+ThreadSanitizer; the device code is compiled as always), and tools/sanitize/host_tables.c drives everything that runs on the host
+before and between kernel launches -- mesh synthesis, the table builders of hmg_grid_create, operator coefficients and cell
+classes, the level-1 assembly, the domain shrink, the partition analysis of every rank -- through the C ABI with a NULL context:
+the uploads are checksummed instead of sent (DryUploads, csrc/hmg_capi.cpp).  No GPU is touched: sanitizers are for the CPU
+build box only.
+
+Checked: no sanitizer report, and the checksums of the would-be device tables are the same for 1 / 3 / 16 setup threads and for
+every byte AddressSanitizer fills fresh heap memory with (a checksum that moves is a race or an uninitialised read).
+"""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "homogenization.jl_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+BAD = ("ERROR: AddressSanitizer", "runtime error:", "ERROR: LeakSanitizer", "WARNING: ThreadSanitizer", "ThreadSanitizer:")
+
+pytestmark = [pytest.mark.slow,
+              pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("make") is None, reason="no ROCm clang / make")]
+
+
+def _harness(kind, tmp_path):
+    subprocess.run(["make", "-C", CSRC, "-j8", kind], check=True, capture_output=True, text=True)
+    libdir = os.path.join(CSRC, "build", kind)
+    exe = str(tmp_path / f"host_tables_{kind}")
+    san = "-fsanitize=address,undefined" if kind == "asan" else "-fsanitize=thread"
+    subprocess.run([CLANG, "-std=c99", "-O1", "-g", san, "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tools", "sanitize", "host_tables.c"), "-o", exe, "-L" + libdir, "-lhmg_hip",
+                    "-Wl,-rpath," + libdir], check=True, capture_output=True, text=True)
+    return exe
+
+
+def _run(exe, args, **env):
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    text = out.stdout + out.stderr
+    assert out.returncode == 0 and "host_tables: done" in out.stdout, text[-4000:]
+    assert not any(b in text for b in BAD), text[-4000:]
+    return [l for l in out.stdout.splitlines() if l.startswith("hash ")]
+
+
+def test_host_side_is_clean_under_asan_ubsan_and_its_tables_do_not_depend_on_heap_contents(tmp_path):
+    exe = _harness("asan", tmp_path)
+    ref = None
+    for threads, fill in (("1", "0"), ("16", "255"), ("3", "190")):
+        got = _run(exe, ["24", "6", "8"], HMG_SETUP_THREADS=threads, UBSAN_OPTIONS="print_stacktrace=1",
+                   ASAN_OPTIONS=f"detect_leaks=1:malloc_fill_byte={fill}:max_malloc_fill_size=1073741824")
+        assert len(got) == 13
+        ref = ref or got
+        assert got == ref, (threads, fill)
+    # the whole-mesh analysis on every rank (HMG_PARTITION_ANALYSIS=global) gives the same device tables as the halo analysis
+    assert _run(exe, ["12", "4", "8"], HMG_SETUP_THREADS="16", HMG_PARTITION_ANALYSIS="global") == \
+        _run(exe, ["12", "4", "8"], HMG_SETUP_THREADS="16")
+
+
+def test_threaded_table_builders_are_race_free_under_tsan(tmp_path):
+    exe = _harness("tsan", tmp_path)
+    a = _run(exe, ["24", "5", "8"], HMG_SETUP_THREADS="16", TSAN_OPTIONS="halt_on_error=0")
+    b = _run(exe, ["24", "5", "2"], HMG_SETUP_THREADS="3", TSAN_OPTIONS="halt_on_error=0", HMG_PARTITION_ANALYSIS="global")
+    assert a[:3] == b[:3]          # the unpartitioned grid's tables: the same with 16 and with 3 threads
