@@ -337,6 +337,8 @@ def main():
                     help="V-cycles timed (outside the timed region) before the placement tuner runs: config.placement.ms_per_step_untuned")
     ap.add_argument("--tune-placement", type=int, default=8,
                     help="candidates of hmg_level_tune_placement for the finest level's five vectors (setup, untimed); 0 = off")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="context option for an A/B run (hmg_ctx_set_option), e.g. --option apply_slab2=0; recorded in config.options")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -400,6 +402,9 @@ def main():
     ctx = hmg.Context(local_rank, stream=stream)
     if args.apply_threads is not None:
         ctx.set_option("apply_threads", args.apply_threads)
+    for o in args.option:
+        name, _, value = o.partition("=")
+        ctx.set_option(name, int(value))
     # (dev knobs for A/B runs: HMG_OPTIONS=name=value,... is applied by hmg.Context itself)
 
     L = args.levels
@@ -590,10 +595,11 @@ def main():
                        "coarse_solver": "device CG, Chebyshev(4)-of-Jacobi preconditioner, rtol 1e-13",
                        "coarse_iterations_last": base_level.last_iterations(),
                        "setup_seconds": setup_seconds, "placement": placement,
-                       "residual_norm_after": rnorm},
+                       "residual_norm_after": rnorm, "options": list(args.option),
+                       "spare_vector_bytes": ctx.counter("spare_bytes"), "lazy_top_form": ctx.counter("lazy_top_form")},
             "roofline": {"bound": "hbm",
                          "kernel": ("hmg::k_apply<3,512,13,*,6> (finest-level operator apply, three 512-thread workgroups per CU"
-                                    if L == 6 else "hmg::k_apply_slab<3,1024,*> (finest-level operator apply, rolling LDS window"
+                                    if L == 6 else "hmg::k_apply_slab2<*> (finest-level operator apply, rolling LDS windows filled by loader waves, evaluated by evaluator waves"
                                     if L == 7 else "hmg::k_apply (finest-level operator apply") +
                                    "; per V-cycle: 1 residual, 6 fused CG passes, the local residual with the pending x-updates and the restriction in its "
                                    "epilogue, the residual with the coarse-grid correction staged in the LDS image)",

@@ -126,7 +126,7 @@ struct LevelBufs {
     DevBuf<uint32_t> slab_ld_word, slab_cp_word, slab_rs_word;
     DevBuf<uint16_t> slab_cp_slot, slab_rs_slot;
     DevBuf<double> rtab;   // restriction weights in class-table layout (slab levels)
-    int nslab = 0, slab_lds_nodes = 0;
+    int nslab = 0, slab_lds_nodes = 0, slab_max_surf = 0;
     DevBuf<uint32_t> pos32, pos32w, sweep32, par32, blk_word;
     DevBuf<uint64_t> par64;
     DevBuf<uint16_t> clpos;
@@ -218,6 +218,7 @@ struct hmg_ctx {
     int64_t comm_calls = 0, comm_doubles = 0;
     int64_t small_launches = 0;              // launches of the pipelined small-level apply
     int64_t wave_launches = 0;               // launches of the one-wave-per-cell apply (hmg_ctx_counter)
+    int64_t slab2_launches = 0;              // launches of the role-split slab apply (hmg_apply_slab.hip)
     int64_t spare_bytes = 0;                 // spare direction vectors held by this context's grids (reserve_top_spare)
     int last_top_form = 0;                   // form the last finest-level post-smoother inside hmg_vcycle took: 0 plain, 1 two-update, 2 three-update
     // Level-vector memory handed back by hmg_vec_destroy, kept for the next hmg_vec_create of the same size: on this
@@ -752,6 +753,13 @@ static void upload_levels(hmg_grid *g)
                 }
                 if ((int)ldw.size() != T.nf || (int)cpw.size() != T.nf)
                     throw std::runtime_error("apply slabs: the slab lists do not cover the cell exactly once");
+                // k_apply_slab2 (hmg_apply_slab.hip) takes the interior slots of a slab as one run of consecutive slots
+                for (int sl = 0; sl < B.nslab; ++sl) {
+                    const int b0 = head[sl * 8 + 3] + head[sl * 8 + 5], e0 = head[sl * 8 + 3] + head[sl * 8 + 4];
+                    for (int q = b0 + 1; q < e0; ++q)
+                        if (cps[(size_t)q] != cps[(size_t)q - 1] + 1) throw std::runtime_error("apply slabs: interior slots of a slab are not consecutive");
+                    B.slab_max_surf = std::max(B.slab_max_surf, head[sl * 8 + 5]);
+                }
                 ldw.resize(ldw.size() + TABLE_PAD, 0u);
                 cpw.resize(cpw.size() + TABLE_PAD, 0u);
                 cps.resize(cps.size() + TABLE_PAD, (uint16_t)0);
@@ -1119,6 +1127,7 @@ void set_slab(hmg_grid *g, const LevelDev &lv)
     g->md.slab.cp_slot = B.slab_cp_slot.p;
     g->md.slab.nslab = B.nslab;
     g->md.slab.lds_nodes = B.slab_lds_nodes;
+    g->md.slab.max_surf = B.slab_max_surf;
 }
 
 // every operator apply goes through here: optional HIP-event bracketing for bench.py's roofline
@@ -1497,7 +1506,7 @@ DeferredX smooth(hmg_grid *g, int level, int steps, hmg_vec *x, hmg_vec *b, hmg_
             // 48 B/DOF; the last pass reads one stream more: 56 instead of 48): 8 B/DOF less again (option lazy_top = 2, the
             // default; the spare vector is allocated at first use -- if that fails the form above is taken)
             if (top_form && steps >= 3 && g->ctx->lazy_top > 1 && i == steps - 2 && g->top_spare.n >= (size_t)n) top3 = true;
-            if (top_form && i == steps - 1) g->ctx->last_top_form = top3 ? 2 : 1;
+            if (top_form && i == steps - 1) g->ctx->last_top_form = top3 ? 2 : 1;   // (hmg_vcycle sets it to 0 in front of the post-smoother)
             const bool top3_here = top3 && i == steps - 2;
             a.x2 = i == 0 ? nullptr : (top3 && lazy_top) ? g->top_spare.p : p->d;       // p = r  /  p = r + beta p, beta = rs'/rs
             a.xout = (i == 0 && swap_rp) || lazy_dead || lazy_x2 || lazy_top ? nullptr : top3_here ? g->top_spare.p : p->d;   // (swap_rp: r_0 itself becomes p_0)
@@ -1976,6 +1985,7 @@ void vcycle(hmg_grid *g, int k, int steps, int steps_coarse, hmg_vec **st, bool 
     // (below the top level x is the zero initial guess the level above left -- written only if this level needs it in memory)
     vcycle_down(g, k, steps, st, /*inside=*/true, /*x_zero=*/!top && zero_entry_ok(g, k, steps), steps_coarse);
     vcycle(g, k - 1, steps_coarse, steps_coarse, st, false);
+    if (top) g->ctx->last_top_form = 0;
     vcycle_up(g, k, steps, st, g->ctx->lean_post ? (top ? 1 : 2) : 0);
 }
 
@@ -2380,6 +2390,10 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_wave = 1;    // level 5: one wave per cell where the class-weight cache exists (hmg_apply_wave.hip)
     c->L.wave_grid = 16 * (int64_t)c->L.num_cu;
     c->L.n_wave_launches = &c->wave_launches;
+    c->L.apply_slab2 = 1;   // level 7: one persistent workgroup per CU, loader and evaluator waves (hmg_apply_slab.hip)
+    c->L.n_slab2_launches = &c->slab2_launches;
+    c->L.slab2_grid = 0;
+    c->L.slab2_loaders = 4;   // (same-box A/B at config 5: 117.7 ms old kernel, 117.2-119.0 with 8 loader waves, 113.1-113.6 with 4)
     c->L.apply_pack = 1;    // level 2: four cells per wave
     c->L.apply_small = 1;   // levels 2-4: pipelined one-wave kernel (hmg_apply_small.hip)
     c->L.n_small_launches = &c->small_launches;
@@ -2413,6 +2427,7 @@ int64_t hmg_ctx_counter(hmg_ctx *ctx, const char *name)
     if (!ctx || !name) return -1;
     const std::string n(name);
     if (n == "wave_launches") return ctx->wave_launches;
+    if (n == "slab2_launches") return ctx->slab2_launches;
     if (n == "small_launches") return ctx->small_launches;
     if (n == "comm_calls") return ctx->comm_calls;
     if (n == "device_allocs") return device_allocs().load();
@@ -2448,6 +2463,12 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_small = value != 0;
     else if (n == "weight_cache")          // 1 = default; 0: level 6 combines its class weights per cell (A/B knob)
         ctx->L.weight_cache = value != 0;
+    else if (n == "apply_slab2")           // 1 = default; 0: cells larger than the LDS keep k_apply_slab (A/B knob)
+        ctx->L.apply_slab2 = value != 0;
+    else if (n == "slab2_loaders")         // loader waves of its 16: 4 (default) or 8
+        ctx->L.slab2_loaders = value == 8 ? 8 : 4;
+    else if (n == "slab2_grid")            // its persistent workgroups (0 = default: one per CU; tests: fewer, many cells each)
+        ctx->L.slab2_grid = std::max<int64_t>(0, value);
     else if (n == "apply_wave")            // 1 = default; 0: level 5 keeps the 256-thread kernel (A/B knob)
         ctx->L.apply_wave = value != 0;
     else if (n == "wave_grid")             // persistent waves per CU of the one-wave apply (default 16: what the LDS holds)

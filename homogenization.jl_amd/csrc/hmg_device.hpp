@@ -68,6 +68,7 @@ struct SlabTables {
     const uint32_t *cp_word;     // evaluated slots: i | j<<7 | k<<14 | cls<<21 (decode32w)        (+ TABLE_PAD)
     const uint16_t *cp_slot;     // evaluated slots: storage slot                                  (+ TABLE_PAD)
     int nslab, lds_nodes;
+    int max_surf;                // most surface entries (cp_surf) of any slab
 };
 
 struct MeshDev {
@@ -167,6 +168,10 @@ struct Launch {
     int apply_wave;       // 1 (default): level 5 takes the one-wave-per-cell kernel where the class-weight cache exists
     int64_t wave_grid;    // its grid: waves resident at once (16 per CU)
     int64_t *n_wave_launches;   // counts its launches (hmg_ctx_counter "wave_launches"; tests check that the path is taken)
+    int apply_slab2;      // 1 (default): cells larger than the LDS (level 7) take the role-split persistent kernel (hmg_apply_slab.hip)
+    int64_t *n_slab2_launches;
+    int64_t slab2_grid;   // its grid (0: one workgroup per CU)
+    int slab2_loaders;    // its loader waves: 4 (default) or 8 of the workgroup's 16
     int64_t persistent_waves;   // grid of the one-wave apply instantiations (default 32 per CU: what is resident at once); they
                           // loop over the cells.  Larger than the number of cells = one workgroup per cell
 };
@@ -186,6 +191,9 @@ void launch_apply_args(const Launch &L, const LevelDev &lv, const MeshDev &mesh,
 // one-wave-per-cell path (hmg_apply_wave.hip): can this launch take it / launch it (a.scal, a.mult, a.blockpart filled in)
 bool apply_wave_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
 void launch_apply_wave(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
+// cells larger than the LDS (hmg_apply_slab.hip): one persistent workgroup per CU, loader and evaluator waves
+bool apply_slab2_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a);
+void launch_apply_slab2(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
 // small 3D levels (hmg_apply_small.hip): one persistent, software-pipelined wave per cell
 bool apply_small_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);
 void launch_apply_small(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a, bool fused);

@@ -37,8 +37,28 @@ __global__ void __launch_bounds__(256) k_finalize(const double *__restrict__ par
         if (a.blockpart && !a.cell_list && tid == 0)                                     \
             a.blockpart[2 * (size_t)a.nwork + 8 * cell + (i)] = (double)wall_clock64(); \
     } while (0)
+// k_apply_slab: thread 0 adds up what it spends per phase over the cell's slabs (its own time line, barrier waits included)
+#define HMG_SLAB_T0() const long long _t0 = wall_clock64(); long long _tl = _t0; double _ph[5] = {0, 0, 0, 0, 0}
+#define HMG_SLAB_PHASE(i)                              \
+    do {                                               \
+        const long long _n = wall_clock64();           \
+        _ph[i] += (double)(_n - _tl);                  \
+        _tl = _n;                                      \
+    } while (0)
+#define HMG_SLAB_STORE()                                                                      \
+    do {                                                                                      \
+        if (a.blockpart && tid == 0) {                                                        \
+            double *_o = a.blockpart + 2 * (size_t)a.nwork + 8 * cell;                        \
+            _o[0] = (double)_t0;                                                              \
+            for (int _q = 0; _q < 5; ++_q) _o[1 + _q] = _ph[_q];                              \
+            _o[6] = (double)wall_clock64();                                                   \
+        }                                                                                     \
+    } while (0)
 #else
 #define HMG_STAMP(i)
+#define HMG_SLAB_T0()
+#define HMG_SLAB_PHASE(i)
+#define HMG_SLAB_STORE()
 #endif
 
 // WD: instantiation for the driver integrals (flags bit 3); CG: the folded prolongation stages the coarse column at the even nodes
@@ -782,7 +802,9 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
         const long long n1 = m + 1, n2 = m + 1 - k;
         return (int)((n1 * (n1 + 1) * (n1 + 2) - n2 * (n2 + 1) * (n2 + 2)) / 6);
     };
+    HMG_SLAB_T0();
     __syncthreads();                                                // W complete
+    HMG_SLAB_PHASE(0);                                              // (0: weight table)
     double w0[NDIR];                                                // interior weight row, SGPR-resident
 #pragma unroll
     for (int d = 0; d < NDIR; ++d) w0[d] = to_sgpr(W[d]);
@@ -830,6 +852,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
         }
         for (int q = (sl > 0 ? plane_off(k0 + 1) - lo : 0) + tid; q < st.lds_nodes; q += NT) img[q] = 0.0;   // stale data + guard
         __syncthreads();
+        HMG_SLAB_PHASE(1);                                          // (1: window move + zero fill, with the wait for the previous slab's consumers)
         // planes new in the window: HBM -> LDS, every slot once; batches of HB slots per thread, all loads of a
         // batch before its stores (xout / xacc may alias x2)
         for (int q0 = 0; q0 < ld_cnt; q0 += HB * NT) {
@@ -878,6 +901,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
         uint32_t q0 = st.cp_word[ib + tid], q1 = st.cp_word[ib + tid + NT];
         int t0 = (int)st.cp_slot[ib + tid], t1 = (int)st.cp_slot[ib + tid + NT];
         __syncthreads();
+        HMG_SLAB_PHASE(2);                                          // (2: HBM -> LDS, to the barrier behind it)
         const int nit_s = (cp_surf + NT - 1) / NT;
         for (int it = 0; it < nit_s; ++it) {
             const int v = it * NT + tid;
@@ -904,6 +928,7 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
                 }
             }
         }
+        HMG_SLAB_PHASE(3);                                          // (3: surface entities)
         const int n_int = cp_cnt - cp_surf;
         const int nit_i = (n_int + NT - 1) / NT;
         for (int it = 0; it < nit_i; ++it) {                        // cell interior: one weight row for all nodes
@@ -926,7 +951,9 @@ k_apply_slab(LevelDev lv, const double *__restrict__ coef, const uint16_t *__res
             }
         }
         lo_prev = lo;
+        HMG_SLAB_PHASE(4);                                          // (4: cell interior)
     }
+    HMG_SLAB_STORE();
     if (FUSED) {
         __syncthreads();
         const double s_pap = block_sum(pap, smem);
@@ -1059,6 +1086,12 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
     }
     if (lds > 160 * 1024) {
         if (DIM != 3 || !mesh.slab.head) throw std::runtime_error("operator apply: cell does not fit the LDS");
+        if constexpr (DIM == 3 && !WD) {
+            if (apply_slab2_ok(L, lv, mesh, a)) {
+                launch_apply_slab2(L, lv, mesh, a, FUSED);
+                return;
+            }
+        }
         auto kern = k_apply_slab<3, 1024, FUSED, WD>;
         const size_t bytes = sizeof(double) * (size_t)(WSZ + mesh.slab.lds_nodes);
         HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1066,6 +1099,7 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
         if (nblocks == 0) return;
         check_apply_bases<FUSED>(a, mesh);
         ApplyArgs b = a;
+        b.nwork = nblocks;
         if (L.cell_order && !a.cell_list && !a.ncells_prefix && mesh.cell_perm) {   // (XCD-aware cell order, as in launch_apply_generic)
             b.cell_list = mesh.cell_perm;
             b.ncell_list = nblocks;

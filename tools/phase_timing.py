@@ -42,6 +42,40 @@ ctx.sync()
 raw = g.table_f64("phase_stamps")
 st = raw[2 * g.ncells():].reshape(-1, 8)[: g.ncells(), :7]
 tick = 10.0  # ns per wall_clock64 tick (100 MHz)
+if g.nf(L) > 20000 and ctx.counter("slab2_launches") > 0:
+    # k_apply_slab2 (hmg_apply_slab.hip): one persistent workgroup per CU; thread 0 (a loader) and thread 512 (an evaluator)
+    # add up their work and their barrier waits over all the (cell, slab) steps of the workgroup
+    nwg = min(g.ncells(), 256)
+    rec = raw[2 * g.ncells(): 2 * g.ncells() + 16 * nwg].reshape(nwg, 16)
+    ld, ev = rec[:, :8], rec[:, 8:]
+    life = (ld[:, 5] - ld[:, 0]) * tick / 1e3
+    print(f"slab2 kernel, mode {a.mode}: workgroups {nwg}, {g.ncells() / nwg:.1f} cells each; kernel span "
+          f"{(max(ld[:, 5].max(), ev[:, 5].max()) - min(ld[:, 0].min(), ev[:, 0].min())) * tick / 1e6:.3f} ms; workgroup lifetime mean {life.mean():.1f} us")
+    for name, col, arr in (("loaders: filling windows", 1, ld), ("loaders: waiting at the step barrier", 2, ld),
+                           ("evaluators: cell interior", 1, ev), ("evaluators: surface entities", 2, ev),
+                           ("evaluators: waiting at the step barrier", 3, ev), ("evaluators: first window", 4, ev)):
+        d = arr[:, col] * tick / 1e3
+        print(f"  {name:44s} mean {d.mean():9.1f} us  ({100 * d.mean() / life.mean():4.1f} %)   per cell {d.mean() / (g.ncells() / nwg):7.2f} us")
+    cy = raw[2 * g.ncells() + 16 * nwg: 2 * g.ncells() + 20 * nwg].reshape(nwg, 4)
+    n = cy[:, 3].sum()
+    if n > 0:
+        print(f"  one interior node evaluation (first of a chunk, wave 8), shader cycles: decode + addresses {cy[:, 0].sum() / n:6.0f}   "
+              f"15 LDS reads + wait {cy[:, 1].sum() / n:6.0f}   17 FP64 ops + store {cy[:, 2].sum() / n:6.0f}   ({n:.0f} samples)")
+    sys.exit(0)
+if g.nf(L) > 20000:
+    # k_apply_slab (cells larger than the LDS): thread 0's time per phase summed over the cell's slabs, barrier waits included
+    names = ["weight table", "window move + zero fill (+ wait for the previous slab)", "HBM -> LDS (to its barrier)",
+             "surface entities", "cell interior"]
+    life = (st[:, 6] - st[:, 0]) * tick / 1e3
+    print(f"slab kernel, mode {a.mode}: workgroups {st.shape[0]}; kernel span {(st[:, 6].max() - st[:, 0].min()) * tick / 1e6:.3f} ms; "
+          f"workgroup lifetime mean {life.mean():.1f} us (p10 {np.percentile(life, 10):.1f}, p90 {np.percentile(life, 90):.1f})")
+    for i, n in enumerate(names):
+        d = st[:, 1 + i] * tick / 1e3
+        print(f"  {n:56s} mean {d.mean():7.2f} us  ({100 * d.mean() / life.mean():4.1f} %)   p10 {np.percentile(d, 10):7.2f}   p90 {np.percentile(d, 90):7.2f}")
+    s0 = np.sort(st[:, 0])
+    nres = a.nres or 512
+    print(f"  per-slot period: {(s0[-1] - s0[0]) * tick / 1e3 / (len(s0) / nres):.2f} us for {nres} resident workgroups")
+    sys.exit(0)
 d = np.diff(st, axis=1) * tick / 1e3
 names = ["W table + column load -> LDS", "table prefetch", "barrier wait", "surface loop", "interior loop",
          "epilogue (reductions)"]
