@@ -57,11 +57,10 @@ def cpu_baseline(sample_width, levels, steps_top):
                       f"threads, serial interface sum) on a {sample_width}^3-cube sub-domain "
                       f"({m.nelements()} cells = {frac:.3g} of BASELINE config 3's 196608), L={levels}, {dt:.2f} s",
             "sample_fraction_of_config3": frac,
-            # the WHOLE of config 3 through the same oracle, measured once on a GPU box's 16 host cores (needs ~90 GB of
-            # host memory and 66 s per V-cycle, too long for every bench run): tests/test_gpu_fullsize.py,
-            # profiles/r02_config3_driver_vs_oracle.txt
-            "full_size_reference": {"value": 1.287e9 / 66.8, "seconds_per_vcycle": 66.8, "cores": 16,
-                                    "source": "profiles/r02_config3_driver_vs_oracle.txt (round 2, one box)"}}
+            # the WHOLE of config 3 through the same oracle needs ~90 GB of host memory and about a minute per V-cycle -- too long
+            # for a bench run; tests/test_gpu_fullsize.py::test_vcycle_matches_oracle_full_size does it (and prints the oracle's time
+            # with -s): re-measured in round 5, profiles/r05_config3_oracle_fullsize.txt
+            "full_size": "profiles/r05_config3_oracle_fullsize.txt"}
 
 
 def time_to_tolerance(ctx, hmg, driver, n, refinements, tolerance):
@@ -78,8 +77,8 @@ def time_to_tolerance(ctx, hmg, driver, n, refinements, tolerance):
             "solve_seconds": tm["solve_s"],
             "vcycles": tm["vcycles"], "outer_steps": tm["outer_steps"], "sigma": sigma,
             "inexact_vcycles": tm["inexact_vcycles"],      # level-1 solves that ran out of their iteration budget
-            "placement": "level vectors as allocated: the driver leaves hmg_level_tune_placement off (tuning costs more than 18 "
-                         "V-cycles gain) -- compare config.placement.ms_per_step_untuned, not ms_per_step",
+            "placement": "level vectors as allocated, like the headline ms_per_step: the driver leaves hmg_level_tune_placement off "
+                         "(tuning costs more than 18 V-cycles gain)",
             "base_mesh": f"{tm['width']}^3 unit cubes, {tm['cells']} cells",
             "level_vector_memory": "blocks the context kept when the bench's own level vectors were destroyed (option "
                                    "vec_pool; a fresh process allocates them in ~0.2 s, DESIGN.md section 4)"}
@@ -333,10 +332,11 @@ def main():
     ap.add_argument("--apply-threads", type=int, default=None)
     ap.add_argument("--no-level-report", dest="level_report", action="store_false",
                     help="skip the per-level breakdown (roofline.levels), measured after the timed region")
-    ap.add_argument("--untuned-burst", type=int, default=3,
-                    help="V-cycles timed (outside the timed region) before the placement tuner runs: config.placement.ms_per_step_untuned")
+    ap.add_argument("--tuned-burst", type=int, default=5,
+                    help="V-cycles timed behind the placement tuner (outside the timed region): config.placement.ms_per_step_tuned")
     ap.add_argument("--tune-placement", type=int, default=8,
-                    help="candidates of hmg_level_tune_placement for the finest level's five vectors (setup, untimed); 0 = off")
+                    help="candidates of hmg_level_tune_placement for the finest level's five vectors, tried BEHIND the timed region and "
+                         "reported under config.placement (the headline is untuned); 0 = off")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="context option for an A/B run (hmg_ctx_set_option), e.g. --option apply_slab2=0; recorded in config.options")
     args = ap.parse_args()
@@ -447,31 +447,6 @@ def main():
     top = states[-1]
     placement = {"tuned": False}
     base_level = prob.base_level() if (world > 1 or force_part) else hmg.BaseLevel(implicit)
-    if args.tune_placement > 0 and args.untuned_burst > 0:
-        # the V-cycle as the allocator happened to place the level vectors (what the driver's checkerboard_homogenization runs):
-        # a short burst before the tuner moves anything
-        top.x.rand(1234, cell_offset=rank * ne_local)
-        hmg.broadcast_interfaces(top.x, implicit, L)
-        hmg.apply_constraint(top.x, L, implicit)
-        hmg.rhs_axi_grad_v(top.b, implicit, driver.random_unit_vec(3))
-        hmg.vcycle(implicit, base_level, [op] * L, states, L, args.smoothing_steps)
-        ctx.sync()
-        t_u = time.perf_counter()
-        for _ in range(args.untuned_burst):
-            hmg.vcycle(implicit, base_level, [op] * L, states, L, args.smoothing_steps)
-        ctx.sync()
-        placement["ms_per_step_untuned"] = 1e3 * (time.perf_counter() - t_u) / args.untuned_burst
-        placement["untuned_burst_steps"] = args.untuned_burst
-    if args.tune_placement > 0:
-        # setup, like an FFT plan: which of the finest level's memory blocks (+ 2 spare ones, freed again) plays x, b, r, p,
-        # Ap is chosen by timing that level's share of a V-cycle per candidate (include/hmg.h, hmg_level_tune_placement)
-        ctx.sync()
-        t_tune0 = time.perf_counter()
-        before, after = hmg.tune_placement(implicit, [op] * L, states, L, args.smoothing_steps, trials=args.tune_placement, extra=2)
-        ctx.sync()
-        placement = {**placement, "tuned": True, "candidates": args.tune_placement, "spare_blocks": 2,
-                     "finest_level_share_of_a_vcycle_ms_as_allocated": before, "finest_level_share_of_a_vcycle_ms_chosen": after,
-                     "seconds": time.perf_counter() - t_tune0}
     top.x.rand(1234, cell_offset=rank * ne_local)
     hmg.broadcast_interfaces(top.x, implicit, L)
     hmg.apply_constraint(top.x, L, implicit)
@@ -490,7 +465,8 @@ def main():
         hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
     barrier()
     comm0 = prob.exchange.stats() if (world > 1 or force_part) else (0, 0)
-    ctx.set_option("time_apply", L)          # HIP events around the finest-level operator applies
+    # The timed region: K V-cycles on the level vectors as the allocator placed them -- what driver.checkerboard_homogenization runs
+    # -- with nothing of the measurement inside (round 5: the HIP events of the roofline and the placement tuner moved behind it).
     t0 = time.perf_counter()
     for _ in range(args.steps):
         hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
@@ -502,9 +478,14 @@ def main():
         ncalls, ndoubles = ex.stats()
         print(f"[rank {rank}] exchange ({ex.backend}): {ncalls} collectives, {ndoubles * 8 / 1e6:.1f} MB, "
               f"{ex.seconds:.3f} s host time inside them (warm-up included)", file=sys.stderr, flush=True)
+    rnorm = hmg.norm_unique(top.r)            # first copies only; summed over ranks by the library
+    # roofline of the dominant kernel: two more V-cycles with HIP events around the finest-level operator applies (events of the
+    # library's own stream, include/hmg.h "time_apply")
+    ctx.set_option("time_apply", L)
+    for _ in range(2):
+        hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
     launches, ms, nbytes = ctx.apply_timing()
     ctx.set_option("time_apply", 0)
-    rnorm = hmg.norm_unique(top.r)            # first copies only; summed over ranks by the library
 
     # Outside the timed region: every level's operator applies between HIP events (two more V-cycles with the timer on for all
     # levels -- inside the timed region only the finest level is timed, an event pair per launch of the launch-bound small levels
@@ -535,6 +516,27 @@ def main():
                                "apply_algorithmic_GB_per_vcycle": by_k / nrep / 1e9,
                                "apply_TBps": (by_k / 1e12) / (ms_k * 1e-3) if ms_k > 0 else None,
                                "level_share_ms": from_level[k] - from_level.get(k - 1, 0.0)})
+
+    if args.tune_placement > 0 and world == 1 and not force_part:
+        # An option of the library, reported beside the headline, never in it: which of the finest level's memory blocks (+ 2 spare
+        # ones, freed again) plays x, b, r, p, Ap is chosen by timing that level's share of a V-cycle per candidate (include/hmg.h,
+        # hmg_level_tune_placement) -- like an FFT plan.  It costs more than 18 V-cycles gain, so the driver leaves it off.
+        ctx.sync()
+        t_tune0 = time.perf_counter()
+        before, after = hmg.tune_placement(implicit, [op] * L, states, L, args.smoothing_steps, trials=args.tune_placement, extra=2)
+        ctx.sync()
+        t_tune = time.perf_counter() - t_tune0
+        hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
+        ctx.sync()
+        t_b = time.perf_counter()
+        for _ in range(args.tuned_burst):
+            hmg.vcycle(implicit, base_level, ops, states, L, args.smoothing_steps)
+        ctx.sync()
+        placement = {"tuned": False, "note": "ms_per_step / value are measured on the level vectors as allocated; the tuned figure is an "
+                     "option's effect, measured behind the timed region", "candidates": args.tune_placement, "spare_blocks": 2,
+                     "finest_level_share_of_a_vcycle_ms_as_allocated": before, "finest_level_share_of_a_vcycle_ms_chosen": after,
+                     "tuner_seconds": t_tune, "ms_per_step_tuned": 1e3 * (time.perf_counter() - t_b) / args.tuned_burst,
+                     "tuned_burst_steps": args.tuned_burst}
 
     dt_rank_min = dt_rank_max = dt
     if dist is not None:

@@ -68,7 +68,7 @@ constexpr int S2_TAB = 128;        // doubles (= 256 ints) of per-slab constants
 constexpr int S2_MAXSLAB = 16;
 constexpr int S2_MAXCELLS = 512;   // cells per workgroup whose ids are staged in LDS (more: the launch takes k_apply_slab)
 __host__ __device__ constexpr int s2_smax(int nlw) { return nlw == 4 ? 4 : 6; }   // rows (of NE) of surface entries per slab (more: k_apply_slab)
-constexpr int S2_U_MAX = 4;        // interior rows per evaluator chunk (launches with a source vector: 2 -- their values take registers)
+constexpr int S2_U_MAX = 4;        // interior rows per evaluator chunk
 // loader: a row is R x 256 slots -- the scalar bookkeeping of a row is paid once per R slots of a lane; D rows lie between the request
 // of a row's data and its use (its addressing words: twice that).  NS streams of 8 B per slot, 256 lanes: 48 / 64 / 72 KB in flight
 // per CU -- 25 / 49 / 49 KB, what 13 GB/s per CU (the share of 3.3 TB/s read) need at 2-4 us of loaded latency -- in 48-72 VGPRs of ring
@@ -219,7 +219,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
 {
     constexpr int NDIR = 15, NTERM = 7;
     constexpr int NL = 64 * NLW, NE = S2_NT - NL, S2_SMAX = s2_smax(NLW);
-    constexpr int S2_U = SRC ? 2 : S2_U_MAX;
+    constexpr int S2_U = S2_U_MAX;
     constexpr bool PIPE = false;     // interior: node q + 1's LDS reads in flight during node q's arithmetic (issue15 / wait15).  Measured round 5:
                                      // no gain (27.2 vs 28.0 us per cell) and WRONG results -- the compiler moved the unwaited values; kept for the record
     extern __shared__ double smem[];
