@@ -80,12 +80,6 @@ __device__ __forceinline__ uint32_t lds_addr(const double *p)
     return (uint32_t)(uintptr_t)(const lds_f64 *)p;
 }
 
-// A global store the compiler does not count (see the head of the file).  The data registers must outlive the issue: s_nop 1.
-__device__ __forceinline__ void st_global(double *p, double v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v));
-}
-
 // 15 LDS reads of an interior node's stencil, issued back to back, ONE wait (form (i) of the guide's asm rules: loads and their
 // s_waitcnt in one statement, early-clobber outputs).  ap = LDS byte address of the node.  Tap order of stencil_eval_v.
 __device__ __forceinline__ void read15(uint32_t ap, int len, int A, int B, double (&v)[15])

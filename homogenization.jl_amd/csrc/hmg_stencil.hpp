@@ -33,6 +33,16 @@ constexpr int WSZ_RB = 64; // ... of the register-blocked instantiations: only t
 // one-wave level-4 kernel rounded x += alpha p twice, k_cg_xp_update once).
 __device__ __forceinline__ double axpy1(double a, double x, double y) { return __builtin_fma(a, x, y); }   // a x + y
 
+// A global store the compiler does not COUNT.  In a loop that requests the next item's loads before it stores the current item's
+// results, a compiler-visible store between a load and its first use on SOME control-flow path turns the wait for that load into a
+// vmcnt(0) -- the store's round trip to L2 (~2000 cycles) per item (measured on the level-7 kernel, profiles/r05_level7_phase_timing.txt).
+// As an asm statement the store is invisible to that bookkeeping: the waits see loads only and stay exact, or err towards one more
+// LOAD.  The data registers must outlive the issue: s_nop 1 (guide section 5.7).
+__device__ __forceinline__ void st_global(double *p, double v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v));
+}
+
 // ---------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------
