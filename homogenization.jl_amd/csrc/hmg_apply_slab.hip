@@ -622,7 +622,8 @@ bool apply_slab2_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, co
     // (flags bit 2, the restriction through the window, keeps k_apply_slab: its evaluation lists do not hold consecutive slots;
     //  bit 3, the driver integrals, has its own instantiations there)
     if (!L.apply_slab2 || lv.dim != 3 || lv.ncls != 15 || !mesh.slab.head || mesh.slab.nslab < 2 || mesh.slab.nslab > S2_MAXSLAB ||
-        mesh.slab.max_surf > s2_smax(L.slab2_loaders == 8 ? 8 : 4) * (S2_NT - 64 * (L.slab2_loaders == 8 ? 8 : 4)) || (a.flags & (4 | 8)) || a.out_ld)
+        mesh.slab.max_surf > s2_smax(L.slab2_loaders == 8 ? 8 : 4) * (S2_NT - 64 * (L.slab2_loaders == 8 ? 8 : 4)) || (a.flags & (4 | 8)) || a.out_ld ||
+        a.xcoarse || a.rcoarse)      // (level transfers folded into an apply: the LDS-resident kernels of levels 5 and 6 only)
         return false;
     return slab2_lds_bytes(mesh) <= 160 * 1024;
 }

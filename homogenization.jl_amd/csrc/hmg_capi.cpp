@@ -2393,6 +2393,7 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.apply_slab2 = 1;   // level 7: one persistent workgroup per CU, loader and evaluator waves (hmg_apply_slab.hip)
     c->L.n_slab2_launches = &c->slab2_launches;
     c->L.slab2_grid = 0;
+    c->L.slab2_force = 0;
     c->L.slab2_loaders = 4;   // (same-box A/B at config 5: 117.7 ms old kernel, 117.2-119.0 with 8 loader waves, 113.1-113.6 with 4)
     c->L.apply_pack = 1;    // level 2: four cells per wave
     c->L.apply_small = 1;   // levels 2-4: pipelined one-wave kernel (hmg_apply_small.hip)
@@ -2467,6 +2468,8 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.apply_slab2 = value != 0;
     else if (n == "slab2_loaders")         // loader waves of its 16: 4 (default) or 8
         ctx->L.slab2_loaders = value == 8 ? 8 : 4;
+    else if (n == "slab2_force")           // experiment: level 6 through the window kernel (needs HMG_SLAB_LDS_KB <= 30 at grid creation)
+        ctx->L.slab2_force = value != 0;
     else if (n == "slab2_grid")            // its persistent workgroups (0 = default: one per CU; tests: fewer, many cells each)
         ctx->L.slab2_grid = std::max<int64_t>(0, value);
     else if (n == "apply_wave")            // 1 = default; 0: level 5 keeps the 256-thread kernel (A/B knob)

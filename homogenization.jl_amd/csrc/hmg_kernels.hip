@@ -1084,7 +1084,11 @@ static void launch_apply_dim(const Launch &L, const LevelDev &lv, const MeshDev 
             return;
         }
     }
-    if (lds > 160 * 1024) {
+    // (experiment of round 5, option slab2_force + HMG_SLAB_LDS_KB <= 30: level 6 through the role-split window kernel of level 7 --
+    //  VERDICT r4 item 4's "cell as two half-images, the second half's loads in flight while the first is evaluated")
+    const bool force_slab2 = DIM == 3 && !WD && L.slab2_force && mesh.slab.head && mesh.slab.nslab >= 2 && lv.nf > 2048 &&
+                             !a.xcoarse && !a.rcoarse && !(a.flags & (4 | 8));
+    if (lds > 160 * 1024 || force_slab2) {
         if (DIM != 3 || !mesh.slab.head) throw std::runtime_error("operator apply: cell does not fit the LDS");
         if constexpr (DIM == 3 && !WD) {
             if (apply_slab2_ok(L, lv, mesh, a)) {
