@@ -66,7 +66,7 @@ constexpr int S2_WSZ = 15 * S2_WROW;
 constexpr int S2_RED = 16;         // per cell parity: 12 evaluator waves' p.Ap, 4 loader waves' r.r
 constexpr int S2_TAB = 128;        // doubles (= 256 ints) of per-slab constants: 16 slabs x 16 ints
 constexpr int S2_MAXSLAB = 16;
-constexpr int S2_MAXCELLS = 512;   // cells per workgroup whose ids are staged in LDS (more: the launch takes k_apply_slab)
+constexpr int S2_MAXCELLS = 1024;  // cells per workgroup whose ids are staged in LDS (more: the launch takes k_apply_slab)
 __host__ __device__ constexpr int s2_smax(int nlw) { return nlw == 4 ? 4 : 6; }   // rows (of NE) of surface entries per slab (more: k_apply_slab)
 constexpr int S2_U_MAX = 4;        // interior rows per evaluator chunk
 // loader: a row is R x 256 slots -- the scalar bookkeeping of a row is paid once per R slots of a lane; D rows lie between the request
