@@ -17,7 +17,7 @@ stats = one("trace/*/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(dst, f"{tag}_vcycle_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-time-to-tolerance (setup with 4 untuned V-cycles and the placement tuner, 1 + 2 V-cycles, 2 more with every level timed, the level shares)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-time-to-tolerance (1 + 2 V-cycles, 2 with HIP events around the finest-level applies, 2 with every level timed, the level shares, the placement tuner + 6 V-cycles)\n")
     f.write("name,calls,total_ms,avg_us,min_us,max_us,pct\n")
     for r in rows:
         f.write(f"\"{r['Name']}\",{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e3:.2f},"
