@@ -207,7 +207,7 @@ int hmg_smooth(hmg_grid *grid, int level, int steps, hmg_vec *x, hmg_vec *b, hmg
 int hmg_level_tune_placement(hmg_grid *grid, int level, int steps, hmg_vec **states, int extra, int trials, double *ms_out);
 /* Coarse operator for the current sigma/lambda/boundary: replaces
  * cholesky(assemble_checkerboard(base, cond, lambda)[interior, interior])
- * (src/examples/homogenized_coefficients.jl:259-261) by a device-resident Jacobi-PCG. */
+ * (src/examples/homogenized_coefficients.jl:259-261) by a device-resident CG, preconditioned by Chebyshev iterates of the Jacobi-scaled operator (option "coarse_poly"; 1 = plain Jacobi-PCG). */
 int hmg_coarse_setup(hmg_grid *grid);
 /* level-1 branch of vcycle!                                  (src/multigrid.jl:74-93) */
 int hmg_coarse_solve(hmg_grid *grid, hmg_vec *b1, hmg_vec *x1);

@@ -193,7 +193,7 @@ distribute!(v::HipMatrix, u::Vector{Float64}, implicit) =                      #
     (check(ccall((:hmg_scatter_base, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Cvoid}), v.grid.h, u, v.h)); v)
 
 # level-1 solve: BaseLevel(Float64, cholesky(assemble_checkerboard(...)[interior, interior]), ...) is replaced by the
-# library's device-resident Jacobi-PCG on the same matrix (src/examples/homogenized_coefficients.jl:259-261,
+# library's device-resident Chebyshev-preconditioned CG on the same matrix (src/examples/homogenized_coefficients.jl:259-261,
 # src/multigrid.jl:30-41, :74-93).  Construct one after every change of sigma, lambda or the domain.
 struct HipBaseLevel
     grid::HipGrid
