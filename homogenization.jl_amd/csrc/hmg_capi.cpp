@@ -1689,7 +1689,7 @@ int coarse_budget_for(const hmg_ctx *c, int last_it)
 
 void coarse_pcg(hmg_grid *g)
 {
-    // Jacobi-PCG on (lambda M + K_sigma)[interior, interior] x = b to a relative residual of
+    // CG (preconditioner: coarse_poly Chebyshev iterates of the Jacobi-scaled operator; 1 = plain Jacobi) on (lambda M + K_sigma)[interior, interior] x = b to a relative residual of
     // coarse_rtol; stands in for the reference's CHOLMOD solve (src/multigrid.jl:84).
     // Convergence is decided on the device: k_coarse_pupdate sets a flag once r.r <= rtol^2 b.b and every kernel of
     // the later iterations returns at once, so a fixed number of iterations can be enqueued without a host round trip.

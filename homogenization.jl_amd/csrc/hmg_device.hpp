@@ -257,7 +257,7 @@ void launch_permute(const Launch &L, const LevelDev &lv, int64_t ncells, const d
 void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, double *x, uint64_t seed,
                         int64_t cell_offset);
 
-// Jacobi-PCG pieces for the level-1 system
+// preconditioned-CG pieces (Jacobi / Chebyshev) for the level-1 system
 void launch_coarse_gather_rhs(const Launch &L, const CoarseDev &A, const double *u, double *b);
 void launch_coarse_scatter_sol(const Launch &L, const CoarseDev &A, int64_t nnodes, const double *x, double *u);
 void launch_coarse_init(const Launch &L, const CoarseDev &A, const double *b, double *x, double *r, double *z,

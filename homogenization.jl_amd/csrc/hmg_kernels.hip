@@ -1,6 +1,6 @@
 // HIP kernels for gfx950 (MI355X): per-cell lattice-stencil operator apply, interface sum,
 // Dirichlet / duplicate masks, level transfer, fused CG vector kernels, level-1 gather/scatter and
-// a Jacobi-PCG for the coarse system.  Wave = 64 lanes everywhere.
+// a (Chebyshev-)preconditioned CG for the coarse system.  Wave = 64 lanes everywhere.
 //
 // Reference behaviour reproduced (file:line in the reference checkout):
 //   k_apply, k_apply_slab  src/apply_local_operators.jl:85-133 (+ :7-27 residual, + constraint mask,
@@ -2256,7 +2256,7 @@ void launch_fill_random(const Launch &L, const LevelDev &lv, int64_t ncells, dou
 }
 
 // ---------------------------------------------------------------------------------------------
-// coarse (level-1) Jacobi-PCG on the assembled interior matrix
+// coarse (level-1) preconditioned CG (Jacobi, or Chebyshev iterates of the Jacobi-scaled operator: k_coarse_cheb) on the assembled interior matrix
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_coarse_gather_rhs(const int32_t *__restrict__ interior, int64_t n, const double *__restrict__ u, double *b)
