@@ -199,6 +199,15 @@ def _worker(rank, world, port, dim, shape, levels, q, analysis="global"):
             yl2[rows, cols] = buf2[torch.from_numpy(dst.ravel())].numpy().reshape(dst.shape)
         err = np.abs(yl2 - ysum[:, g.local_cells]).max() / np.abs(ysum).max()
         assert err <= 1e-13, err
+        if global_ids:
+            # The two forms against each other: the sharers-only form adds the members' partials in ascending rank
+            # order; a collective adds them in the order of its algorithm.  Two ranks: one commutative addition per shared DOF
+            # -- the same bits.  More sharers: the same to rounding only (bench.py's preflight reports
+            # `other_form_bit_identical`, never requires it).
+            if world == 2:
+                np.testing.assert_array_equal(yl2, yl)
+            else:
+                assert np.abs(yl2 - yl).max() <= 8 * world * np.finfo(float).eps * np.abs(ysum).max()
         # what it saves: doubles this rank sends vs the all-reduce buffer every rank pushes through the ring
         sent = torch.tensor([float(msgs[:, 2].sum()) if len(msgs) else 0.0, float(tot)], dtype=torch.float64)
         if world == 8 and global_ids:
