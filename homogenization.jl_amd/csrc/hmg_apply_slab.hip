@@ -207,7 +207,9 @@ __device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstla
 
 // NS: streams the loaders read per slot -- 1: x;  2: x and x2 (p-update);  3: x, x2 and xacc or x3 (pending x-updates)
 // SRC / OUT: the launch has a source vector / stores its result (a dead CG step stores nothing)
-template <bool FUSED, int NS, bool SRC, bool OUT, int NLW>
+// SLOT: the interior entries of a slab's evaluation list carry their output slots (the restriction through the window: the even
+// nodes of the lattice, output = their COARSE slots); otherwise they are one run of consecutive slots
+template <bool FUSED, int NS, bool SRC, bool OUT, int NLW, bool SLOT = false>
 __global__ void __launch_bounds__(S2_NT, 4)
 k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__restrict__ dmask, ApplyArgs a, SlabTables st)
 {
@@ -360,12 +362,16 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                             double *W = Wt + (size_t)(cp.ci & 1) * S2_WSZ;
                             if (rt < lv.ncls * NDIR) {
                                 const int cls = rt / NDIR, d = rt - cls * NDIR;
-                                double s[NTERM];
-                                cell_scales<3>(coef + cp.cell * 8, a.alpha, a.lambda, s, a.flags);
-                                const double *c = lv.ctab + (size_t)rt * NTERM;
                                 double w = 0.0;
+                                if (a.flags & 4) {   // cell-independent stencil (restriction): the weight is the last term of the class table
+                                    w = lv.ctab[(size_t)rt * NTERM + NTERM - 1];
+                                } else {
+                                    double s[NTERM];
+                                    cell_scales<3>(coef + cp.cell * 8, a.alpha, a.lambda, s, a.flags);
+                                    const double *c = lv.ctab + (size_t)rt * NTERM;
 #pragma unroll
-                                for (int q = 0; q < NTERM; ++q) w += c[q] * s[q];
+                                    for (int q = 0; q < NTERM; ++q) w += c[q] * s[q];
+                                }
                                 W[cls * S2_WROW + d] = w;
                             } else if (rt < lv.ncls * NDIR + lv.ncls) {
                                 W[(rt - lv.ncls * NDIR) * S2_WROW + 15] = 0.0;        // (row padding: read, never used)
@@ -442,7 +448,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
         // values of this thread's surface entries, words and source values of its first interior chunk.  Rows are completed with
         // copies of their last entry.
         uint32_t sw[S2_SMAX], iw[S2_U];
-        int ss[S2_SMAX];
+        int ss[S2_SMAX], is[S2_U];
         double ssv[S2_SMAX], isv[S2_U];
         uint32_t dm_n = 0, mq_n[4];
         // (absent tables: any readable address -- the values are not used then)
@@ -466,6 +472,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
             for (int q = 0; q < S2_U; ++q) {
                 const int v = max(min(q * NE + rt, n_int - 1), 0);
                 iw[q] = st.cp_word[cp_off + cp_surf + v];
+                if (SLOT) is[q] = (int)st.cp_slot[cp_off + cp_surf + v];
                 if (SRC) isv[q] = sc[t_first + v];
             }
             if (SRC) {
@@ -492,7 +499,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                 for (int d = 0; d < NDIR; ++d) w0[d] = to_sgpr(lds_ld(W + d));   // interior weight row (class 0), SGPR-resident
             }
             const double *sc = SRC ? a.src + cell * lv.ld : nullptr;
-            double *oc = OUT ? a.out + cell * (int64_t)lv.ld : nullptr;
+            double *oc = OUT ? a.out + cell * (a.out_ld ? a.out_ld : (int64_t)lv.ld) : nullptr;
             const int *t = tab + 16 * sl;
             const int cp_off = sgpr(t[8]), cp_surf = sgpr(t[9]), n_int = sgpr(t[10]), t_first = sgpr(t[11]), nrow_i = sgpr(t[12]),
                       nrow_s = sgpr(t[13]), lo = sgpr(t[3]);
@@ -504,11 +511,13 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
             // in front of this chunk's evaluation
             for (int r0 = 0; r0 < nrow_i; r0 += S2_U) {
                 uint32_t nw[S2_U];
+                int ns[S2_U];
                 double nsv[S2_U];
 #pragma unroll
                 for (int q = 0; q < S2_U; ++q) {
                     const int v = min((r0 + S2_U + q) * NE + rt, n_int - 1);
                     nw[q] = st.cp_word[ib + v];
+                    if (SLOT) ns[q] = (int)st.cp_slot[ib + v];
                     if (SRC) nsv[q] = sc[t_first + v];
                 }
                 // node q's arithmetic runs while the LDS serves node q + 1 (issue15 / wait15)
@@ -543,7 +552,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                         for (int d = 2; d < NDIR; ++d) acc = __builtin_fma(w0[d], x[d], acc);
                         const double o = (SRC ? isv[q] : 0.0) + acc;
                         if (v < n_int) {
-                            if (OUT) st_global(oc + t_first + v, o);
+                            if (OUT) st_global(oc + (SLOT ? is[q] : t_first + v), o);
                             if (FUSED) pap = __builtin_fma(x[0], o, pap);
                         }
                     }
@@ -551,6 +560,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
 #pragma unroll
                 for (int q = 0; q < S2_U; ++q) {
                     iw[q] = nw[q];
+                    if (SLOT) is[q] = ns[q];
                     if (SRC) isv[q] = nsv[q];
                 }
             }
@@ -622,16 +632,16 @@ bool apply_slab2_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, co
     // (flags bit 2, the restriction through the window, keeps k_apply_slab: its evaluation lists do not hold consecutive slots;
     //  bit 3, the driver integrals, has its own instantiations there)
     if (!L.apply_slab2 || lv.dim != 3 || lv.ncls != 15 || !mesh.slab.head || mesh.slab.nslab < 2 || mesh.slab.nslab > S2_MAXSLAB ||
-        mesh.slab.max_surf > s2_smax(L.slab2_loaders == 8 ? 8 : 4) * (S2_NT - 64 * (L.slab2_loaders == 8 ? 8 : 4)) || (a.flags & (4 | 8)) || a.out_ld ||
+        mesh.slab.max_surf > s2_smax(L.slab2_loaders == 8 ? 8 : 4) * (S2_NT - 64 * (L.slab2_loaders == 8 ? 8 : 4)) || (a.flags & 8) || (((a.flags & 4) != 0) != (a.out_ld != 0)) ||
         a.xcoarse || a.rcoarse)      // (level transfers folded into an apply: the LDS-resident kernels of levels 5 and 6 only)
         return false;
     return slab2_lds_bytes(mesh) <= 160 * 1024;
 }
 
-template <bool FUSED, int NS, bool SRC, bool OUT>
+template <bool FUSED, int NS, bool SRC, bool OUT, bool SLOT = false>
 static void launch_slab2(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a)
 {
-    auto kern = L.slab2_loaders == 8 ? k_apply_slab2<FUSED, NS, SRC, OUT, 8> : k_apply_slab2<FUSED, NS, SRC, OUT, 4>;
+    auto kern = L.slab2_loaders == 8 ? k_apply_slab2<FUSED, NS, SRC, OUT, 8, SLOT> : k_apply_slab2<FUSED, NS, SRC, OUT, 4, SLOT>;
     const size_t bytes = slab2_lds_bytes(mesh);
     HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;
@@ -654,7 +664,7 @@ void launch_apply_slab2(const Launch &L, const LevelDev &lv, const MeshDev &mesh
     if (!a.x) throw std::runtime_error("operator apply: null input vector");
     if (!fused && !a.out) throw std::runtime_error("operator apply: a plain launch needs an output vector");
     if (fused && (!a.blockpart || !a.scal)) throw std::runtime_error("operator apply: fused launch without its reduction scratch");
-    if (!mesh.coef) throw std::runtime_error("operator apply: no operator coefficients on the device (hmg_grid_set_operator)");
+    if (!mesh.coef && !(a.flags & 4)) throw std::runtime_error("operator apply: no operator coefficients on the device (hmg_grid_set_operator)");
     if ((a.flags & 1) && !mesh.dmask) throw std::runtime_error("operator apply: constraint requested without a Dirichlet mask");
     if (a.xcoarse || a.rcoarse) throw std::runtime_error("operator apply: the slab kernel folds no level transfer");
     if (fused && (a.xacc || a.x3) && !a.x2) throw std::runtime_error("operator apply: a pending x-update without its direction vector");
@@ -663,6 +673,11 @@ void launch_apply_slab2(const Launch &L, const LevelDev &lv, const MeshDev &mesh
         throw std::runtime_error("operator apply: the zero-input form exists for the residual with two pending x-updates only");
     if (L.n_slab2_launches) *L.n_slab2_launches += 1;
     const bool src = a.src != nullptr, out = a.out != nullptr;
+    if (a.flags & 4) {   // the restriction through the window (launch_restrict_slab)
+        if (fused || src || !out || !a.out_ld) throw std::runtime_error("restriction through the window: plain launch with its own column stride");
+        launch_slab2<false, 1, false, true, true>(L, lv, mesh, a);
+        return;
+    }
     if (!fused) {
         if (src)
             launch_slab2<false, 1, true, true>(L, lv, mesh, a);

@@ -171,6 +171,7 @@ struct Launch {
     int apply_slab2;      // 1 (default): cells larger than the LDS (level 7) take the role-split persistent kernel (hmg_apply_slab.hip)
     int64_t *n_slab2_launches;
     int64_t slab2_grid;   // its grid (0: one workgroup per CU)
+    int restrict_slab2;   // 1 (default): the stand-alone restriction of levels with slab tables goes through it too (eight loader waves)
     int slab2_force;      // 1 (experiment): every 3D level with slab tables of two slabs or more takes it (level 6 with HMG_SLAB_LDS_KB <= 30)
     int slab2_loaders;    // its loader waves: 4 (default) or 8 of the workgroup's 16
     int64_t persistent_waves;   // grid of the one-wave apply instantiations (default 32 per CU: what is resident at once); they

@@ -1586,6 +1586,17 @@ void launch_restrict_slab(const Launch &L, const LevelDev &fine_rtab, const Mesh
     a.out = bc;
     a.out_ld = ldc;
     a.flags = 4;
+    {   // round 5: through the role-split window kernel with EIGHT loader waves -- an eighth of the nodes is evaluated (the even ones), so
+        // the loaders set the pace (option restrict_slab2 = 0: k_apply_slab as in rounds 1-4; the coarse vector is the same to the last bit)
+        MeshDev m2 = mesh;
+        m2.slab = st;
+        Launch L2 = L;
+        L2.slab2_loaders = 8;
+        if (L.restrict_slab2 && apply_slab2_ok(L2, fine_rtab, m2, a)) {
+            launch_apply_slab2(L2, fine_rtab, m2, a, false);
+            return;
+        }
+    }
     auto kern = k_apply_slab<3, 1024, false>;
     const size_t bytes = sizeof(double) * (size_t)(WSZ + st.lds_nodes);
     HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

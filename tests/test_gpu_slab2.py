@@ -120,3 +120,25 @@ def test_vcycles_match(case):
     again = run()
     np.testing.assert_array_equal(again[0], new[0])
     np.testing.assert_array_equal(again[1], new[1])
+
+
+def test_restriction_through_the_window_is_bit_identical(case):
+    """restrict_to! of level 7 (src/interpolation.jl:52-62) through k_apply_slab2 (eight loader waves, output slots from the
+    list) against k_apply_slab: the same 15-point sums in the same order -- the coarse vector is equal to the last bit."""
+    ctx, g, A = case
+    xf = hmg.DeviceMatrix(g, L).rand(21)
+    out = []
+    for on in (1, 0):
+        ctx.set_option("restrict_slab2", on)
+        try:
+            n0 = ctx.counter("slab2_launches")
+            rc = hmg.DeviceMatrix(g, L - 1)
+            hmg.restrict_to(rc, g, xf)
+            out.append(rc.to_host())
+            rc.close()
+            assert (ctx.counter("slab2_launches") > n0) == bool(on)
+        finally:
+            ctx.set_option("restrict_slab2", 1)
+    assert np.abs(out[1]).max() > 0
+    np.testing.assert_array_equal(out[0], out[1])
+    xf.close()
