@@ -464,7 +464,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
             const double *sc = SRC ? a.src + cell_n * lv.ld : nullptr;
 #pragma unroll
             for (int q = 0; q < S2_SMAX; ++q) {
-                const int v = min(q * NE + rt, cp_surf - 1);
+                const int v = max(min(q * NE + rt, cp_surf - 1), 0);      // (a slab without surface entries: entry 0, unused)
                 sw[q] = st.cp_word[cp_off + v];
                 ss[q] = (int)st.cp_slot[cp_off + v];
             }

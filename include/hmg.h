@@ -87,6 +87,11 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * level-1 PCG is preconditioned by that many Chebyshev iterates of the Jacobi-scaled operator -- k - 1 sparse products without a
  * reduction per outer iteration --; 1 = plain Jacobi), "weight_cache" / "apply_small" / "apply_pack" (1 = default: class weights of levels 2-6
  * from the class-weight cache; levels 2-4 by the pipelined one-wave kernel, level 2 four cells to a wave, hmg_apply_small.hip),
+ * "apply_slab2" (1 = default: cells larger than the LDS -- 3D level 7 -- are applied by ONE persistent 1024-thread workgroup per CU
+ * whose waves have roles, hmg_apply_slab.hip: loader waves stream the next k-plane window from HBM while evaluator waves work on the
+ * current one; 0 = the rolling-window kernel of rounds 1-4, same arithmetic per node; "slab2_loaders": its loader waves, 4 = default
+ * or 8; "slab2_grid": its workgroups, 0 = one per CU; "restrict_slab2": 1 = default, the stand-alone restriction of such a level goes
+ * through it too; "slab2_force": experiment, level 6 through it -- needs HMG_SLAB_LDS_KB <= 30 when the grid is created),
  * "time_apply"; "coarse_rtol" and "coarse_poly_ratio" (20: the interval [lmax / ratio, lmax]) via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
  * kernel for cells larger than the LDS, default 70). */
 int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value);
@@ -97,7 +102,7 @@ int hmg_ctx_apply_timing(hmg_ctx *ctx, int64_t *launches, double *total_ms, doub
 /* ... the same, only the launches of one level ("time_apply" = 1 times every level). */
 int hmg_ctx_apply_timing_level(hmg_ctx *ctx, int level, int64_t *launches, double *total_ms, double *total_bytes);
 /* diagnostic counters: "wave_launches" (launches of the one-wave-per-cell level-5 apply, hmg_apply_wave.hip), "small_launches"
-   (levels 2-4, hmg_apply_small.hip), "comm_calls", "comm_nranks" (ranks of the RCCL communicator made by hmg_comm_init, 0 without
+   (levels 2-4, hmg_apply_small.hip), "slab2_launches" (level 7, hmg_apply_slab.hip), "comm_calls", "comm_nranks" (ranks of the RCCL communicator made by hmg_comm_init, 0 without
    one), "device_allocs" (device / pinned allocations the library has made in this process: constant across hmg_vcycle once the
    grid, its operator, its level-1 system and the level vectors exist), "spare_bytes" (spare direction vectors held by this
    context's grids, see hmg_grid_reserve_spare), "lazy_top_form" (the form the last finest-level post-smoother inside hmg_vcycle
