@@ -118,3 +118,29 @@ def test_coarse_products_keep_their_row_sums_in_registers(tmp_path):
         assert int(m.group(2)) == 0, m.group(0)[-200:]
         assert int(m.group(3)) <= 128, (m.group(1), m.group(3))
     assert seen == 2
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_slab2_kernel_fits_one_workgroup_per_cu_without_scratch(tmp_path):
+    """hmg_apply_slab.hip: k_apply_slab2<FUSED, NS, SRC, OUT, loader waves, SLOT> (level 7, round 5) -- ONE 1024-thread workgroup per
+    CU: 128 VGPRs per lane.  No instantiation may spill: a spilled value of the loaders' ring or of an asm read batch is a scratch
+    access in the middle of a stream that must not wait (and the software-pipelined read experiment of the round showed what a
+    compiler move of an unwaited asm output does).  Its global stores must be asm statements (csrc/hmg_stencil.hpp st_global): a
+    compiler-visible store inside its loops turned every wait into a drain."""
+    src = os.path.join(ROOT, "homogenization.jl_amd", "csrc", "hmg_apply_slab.hip")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                          "-o", str(tmp_path / "s.o")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    found = {}
+    for m in re.finditer(r"Function Name: _ZN3hmg\w*?13k_apply_slab2I(\w+?)EEvNS_8LevelDev.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)",
+                         out.stderr, re.S):
+        found[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    # <FUSED, NS, SRC, OUT> x loader waves {4, 8}: 14 combinations each, + the restriction form (SLOT)
+    assert len(found) >= 30, sorted(found)
+    for name, (vgprs, scratch) in found.items():
+        assert vgprs <= 128 and scratch == 0, (name, vgprs, scratch)
+    text = open(src).read()
+    body = text[text.index("k_apply_slab2("):text.index("size_t slab2_lds_bytes")]
+    assert "st_global(" in body
+    # no plain store through the output / update pointers inside the kernel
+    assert not re.search(r"\b(a\.xout|a\.xacc|a\.out|oc|bxo|bxa)\s*\[[^\]]+\]\s*=[^=]", body), "compiler-visible global store in k_apply_slab2"
