@@ -61,6 +61,6 @@ def test_host_side_is_clean_under_asan_ubsan_and_its_tables_do_not_depend_on_hea
 
 def test_threaded_table_builders_are_race_free_under_tsan(tmp_path):
     exe = _harness("tsan", tmp_path)
-    a = _run(exe, ["24", "5", "8"], HMG_SETUP_THREADS="16", TSAN_OPTIONS="halt_on_error=0")
-    b = _run(exe, ["20", "5", "2"], HMG_SETUP_THREADS="3", TSAN_OPTIONS="halt_on_error=0", HMG_PARTITION_ANALYSIS="global")
+    a = _run(exe, ["24", "4", "8"], HMG_SETUP_THREADS="16", TSAN_OPTIONS="halt_on_error=0")
+    b = _run(exe, ["16", "4", "2"], HMG_SETUP_THREADS="3", TSAN_OPTIONS="halt_on_error=0", HMG_PARTITION_ANALYSIS="global")
     assert len(a) == 13 and len(b) == 7
