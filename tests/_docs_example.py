@@ -11,7 +11,11 @@ smoother is nonlinear), for every seed, for n = 16 / 32 / 64, lambda = 0 / 1, wi
 FASTER than the printout (residual 6e-7 instead of 4.3e-4 after 100 cycles).  The rate is a strong function of the
 contrast: 0.34 for sigma = 1, 0.80 at contrast 9, 0.95-0.99 at contrast 100, so the printed 0.9105 corresponds to a
 contrast between 9 and 100.  Which code version and coefficient field produced the printout cannot be established
-without running the reference (no Julia here); rows E/F stay "parity unpinned" (DESIGN.md section 6)."""
+without running the reference (no Julia here); rows E/F stay "parity unpinned" (DESIGN.md section 6).
+One clue in the reference's own text (round 5): the tutorial describes LevelState as "x, b and r" (docs/src/index.md:244-247) where
+src/multigrid.jl:7-13 holds five arrays (p and Ap came with the CG smoother), and the reference's stale test/local_operators.jl:60-101
+still calls an earlier `vcycle!(..., level_states, ωs, total_levels)` with per-level damping factors -- the tutorial text, and
+possibly its printout, predate the CG smoother restated here."""
 import numpy as np
 
 REFERENCE_TAIL = (0.0005182895775368055, 0.00047190444233626385, 0.00042970384073489823)   # docs/src/index.md:296-302
