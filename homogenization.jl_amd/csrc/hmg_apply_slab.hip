@@ -66,6 +66,7 @@ constexpr int S2_WSZ = 15 * S2_WROW;
 constexpr int S2_RED = 16;         // per cell parity: 12 evaluator waves' p.Ap, 4 loader waves' r.r
 constexpr int S2_TAB = 128;        // doubles (= 256 ints) of per-slab constants: 16 slabs x 16 ints
 constexpr int S2_MAXSLAB = 16;
+constexpr int S2_GUARD = 72;       // doubles of zeros below window 0: what the in-plane taps of plane 0's first rows address (up to m + 2 entries below the cell)
 constexpr int S2_MAXCELLS = 1024;  // cells per workgroup whose ids are staged in LDS (more: the launch takes k_apply_slab)
 __host__ __device__ constexpr int s2_smax(int nlw) { return nlw == 4 ? 4 : 6; }   // rows (of NE) of surface entries per slab (more: k_apply_slab)
 constexpr int S2_U_MAX = 4;        // interior rows per evaluator chunk
@@ -152,52 +153,65 @@ __device__ __forceinline__ void wait15(double (&v)[15])
                  : "i"(N));
 }
 
-// Surface node: eight taps' values and weights per statement (the weight row: 128-B aligned, stride S2_WROW).  Taps that leave
-// the cell carry zero weights and may address below the image: clamped to its first entry (stencil_eval_c).
-__device__ __forceinline__ void read8(const uint32_t (&ad)[8], uint32_t aw, double (&v)[8], double (&w)[8])
+// Surface node: the interior node's addressing (seven address registers, read15's tap order) and, per statement, eight / seven
+// taps' values and their class weights (the weight row: 128-B aligned, stride S2_WROW).  Taps that leave the cell carry zero
+// weights (host check); what they read is some other entry of the window or the zero guards below / behind it -- finite values.
+// A node of plane k = 0 has no plane below: the caller passes B = 0 (its four lower taps then read the node's own plane).
+__device__ __forceinline__ double surface_eval(uint32_t ap, uint32_t aw, int len, int A, int B, double &ctr)
 {
-    asm volatile("ds_read_b64 %0, %16\n\t"
-                 "ds_read_b64 %1, %17\n\t"
-                 "ds_read_b64 %2, %18\n\t"
-                 "ds_read_b64 %3, %19\n\t"
-                 "ds_read_b64 %4, %20\n\t"
-                 "ds_read_b64 %5, %21\n\t"
-                 "ds_read_b64 %6, %22\n\t"
-                 "ds_read_b64 %7, %23\n\t"
-                 "ds_read_b64 %8, %24\n\t"
-                 "ds_read_b64 %9, %24 offset:8\n\t"
-                 "ds_read_b64 %10, %24 offset:16\n\t"
-                 "ds_read_b64 %11, %24 offset:24\n\t"
-                 "ds_read_b64 %12, %24 offset:32\n\t"
-                 "ds_read_b64 %13, %24 offset:40\n\t"
-                 "ds_read_b64 %14, %24 offset:48\n\t"
-                 "ds_read_b64 %15, %24 offset:56\n\t"
+    const uint32_t a0 = ap - 8u;                                   // p - 1 | p | p + 1
+    const uint32_t a1 = ap + 8u * (uint32_t)(len - 1);             // p + len - 1 | p + len
+    const uint32_t a2 = ap - 8u * (uint32_t)(len + 1);             // p - len - 1 | p - len
+    const uint32_t pu = ap + 8u * (uint32_t)A, pd = ap - 8u * (uint32_t)B;
+    const uint32_t a3 = pu - 8u * (uint32_t)len;                   // pu - len | pu + 1 - len
+    const uint32_t a4 = pu - 8u;                                   // pu - 1 | pu
+    const uint32_t a6 = pd + 8u * (uint32_t)len;                   // pd + len | pd + len + 1
+    double v[8], w[8];
+    asm volatile("ds_read_b64 %0, %16 offset:8\n\t"
+                 "ds_read_b64 %1, %16 offset:16\n\t"
+                 "ds_read_b64 %2, %16\n\t"
+                 "ds_read_b64 %3, %17\n\t"
+                 "ds_read_b64 %4, %18 offset:8\n\t"
+                 "ds_read_b64 %5, %17 offset:8\n\t"
+                 "ds_read_b64 %6, %18\n\t"
+                 "ds_read_b64 %7, %19\n\t"
+                 "ds_read_b64 %8, %20\n\t"
+                 "ds_read_b64 %9, %20 offset:8\n\t"
+                 "ds_read_b64 %10, %20 offset:16\n\t"
+                 "ds_read_b64 %11, %20 offset:24\n\t"
+                 "ds_read_b64 %12, %20 offset:32\n\t"
+                 "ds_read_b64 %13, %20 offset:40\n\t"
+                 "ds_read_b64 %14, %20 offset:48\n\t"
+                 "ds_read_b64 %15, %20 offset:56\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(w[0]),
                    "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]), "v"(aw));
-}
-
-// (the arithmetic of stencil_eval_c as hipcc compiles it: the product of tap 1 is rounded, tap 0 joins it by a fused multiply-add,
-//  then one fused multiply-add per tap in tap order)
-__device__ __forceinline__ double surface_eval(uint32_t img_addr, int lo, uint32_t wrow_addr, int L, int len, int A, int B, double &ctr)
-{
-    // LDS byte address of lattice position q of the cell (window base img_addr holds lattice position lo); below the image: its first entry
-    auto at = [&](int off) { return img_addr + 8u * (uint32_t)(max(L + off, 0) - lo); };
-    double v[8], w[8];
-    {
-        const uint32_t ad[8] = {at(0), at(1), at(-1), at(len - 1), at(-len), at(len), at(-len - 1), at(A - len)};
-        read8(ad, wrow_addr, v, w);
-    }
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(aw));
+    // (the arithmetic of stencil_eval_c as hipcc compiles it: the product of tap 1 is rounded, tap 0 joins it by a fused multiply-add,
+    //  then one fused multiply-add per tap in tap order)
     ctr = v[0];
     double acc = w[1] * v[1];
     acc = __builtin_fma(w[0], ctr, acc);
 #pragma unroll
     for (int d = 2; d < 8; ++d) acc = __builtin_fma(w[d], v[d], acc);
-    {
-        const uint32_t ad[8] = {at(len + 1 - B), at(A - 1), at(1 - B), at(A), at(-B), at(A + 1 - len), at(len - B), at(0)};
-        read8(ad, wrow_addr + 64u, v, w);      // (the eighth pair of the second half is padding: weight row entry 15, never used)
-    }
+    asm volatile("ds_read_b64 %0, %17 offset:8\n\t"
+                 "ds_read_b64 %1, %15\n\t"
+                 "ds_read_b64 %2, %16 offset:8\n\t"
+                 "ds_read_b64 %3, %15 offset:8\n\t"
+                 "ds_read_b64 %4, %16\n\t"
+                 "ds_read_b64 %5, %14 offset:8\n\t"
+                 "ds_read_b64 %6, %17\n\t"
+                 "ds_read_b64 %7, %18 offset:64\n\t"
+                 "ds_read_b64 %8, %18 offset:72\n\t"
+                 "ds_read_b64 %9, %18 offset:80\n\t"
+                 "ds_read_b64 %10, %18 offset:88\n\t"
+                 "ds_read_b64 %11, %18 offset:96\n\t"
+                 "ds_read_b64 %12, %18 offset:104\n\t"
+                 "ds_read_b64 %13, %18 offset:112\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(w[0]), "=&v"(w[1]),
+                   "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6])
+                 : "v"(a3), "v"(a4), "v"(pd), "v"(a6), "v"(aw));
 #pragma unroll
     for (int d = 0; d < 7; ++d) acc = __builtin_fma(w[d], v[d], acc);
     return acc;
@@ -223,7 +237,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
     double *red = smem + 2 * S2_WSZ;                // [2][S2_RED]
     int *tab = (int *)(red + 2 * S2_RED);           // [S2_MAXSLAB][16] per-slab constants (below)
     int *cells = tab + 2 * S2_TAB;                  // [S2_MAXCELLS] this workgroup's cells (no global load, hence no wait, at a cell change)
-    double *img0 = red + 2 * S2_RED + S2_TAB + S2_MAXCELLS / 2;   // [2][win]     the two windows
+    double *img0 = red + 2 * S2_RED + S2_TAB + S2_MAXCELLS / 2 + S2_GUARD;   // [2][win]     the two windows, S2_GUARD zeros below
     const int win = st.lds_nodes;
     const int tid = threadIdx.x;
     const int wave = sgpr(tid >> 6);
@@ -233,6 +247,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
     const int64_t G = gridDim.x, b0 = blockIdx.x;
     const int64_t ncl = (a.nwork - b0 + G - 1) / G;                 // cells of this workgroup: b0, b0 + G, ..
     const int64_t T = ncl * nsl;                                    // steps: (cell, slab) pairs
+    if (tid < S2_GUARD) img0[tid - S2_GUARD] = 0.0;
     for (int64_t ci = tid; ci < ncl; ci += S2_NT) {
         const int64_t idx = b0 + ci * G;
         cells[ci] = a.cell_list ? a.cell_list[idx] : (int)idx;
@@ -438,6 +453,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
         // EVALUATORS: at iteration g they evaluate step g from window g & 1
         // ------------------------------------------------------------------------------------------------------------------
         const uint32_t img_a0 = lds_addr(img0);
+        const int wbase = (wave - NLW) * 64;        // first entry of this wave in a row of NE
         double pap = 0.0;
         int64_t ci = 0;
         int sl = 0;
@@ -502,7 +518,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
             double *oc = OUT ? a.out + cell * (a.out_ld ? a.out_ld : (int64_t)lv.ld) : nullptr;
             const int *t = tab + 16 * sl;
             const int cp_off = sgpr(t[8]), cp_surf = sgpr(t[9]), n_int = sgpr(t[10]), t_first = sgpr(t[11]), nrow_i = sgpr(t[12]),
-                      nrow_s = sgpr(t[13]), lo = sgpr(t[3]);
+                      lo = sgpr(t[3]);
             const uint32_t img_a = img_a0 + (uint32_t)b * 8u * (uint32_t)win;     // LDS byte address of lattice position lo
             const uint32_t w_a = lds_addr(Wt + (size_t)(ci & 1) * S2_WSZ);
             const int ib = cp_off + cp_surf;
@@ -533,7 +549,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                     double (&x)[15] = (q & 1) ? xb : xa;
                     double (&xn)[15] = (q & 1) ? xa : xb;
                     const bool more = q + 1 < S2_U && r0 + q + 1 < nrow_i;      // (uniform)
-                    if (r0 + q < nrow_i) {
+                    if ((r0 + q) * NE + wbase < n_int) {                          // (this wave's 64 entries of the row: none beyond the list)
                         if (!PIPE) {
                             int L, len, A, B;
                             decode_lattice(iw[q], m, L, len, A, B);
@@ -568,12 +584,12 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
             // surface entities: the class weight row comes from the LDS table
 #pragma unroll
             for (int q = 0; q < S2_SMAX; ++q) {
-                if (q < nrow_s) {
+                if (q * NE + wbase < cp_surf) {                       // (a wave none of whose 64 entries is in the list skips the row)
                     const int v = q * NE + rt;
                     int L, len, A, B, cls, k;
                     decode32w(sw[q], m, L, len, A, B, cls, k);
                     double ctr;
-                    double o = surface_eval(img_a, lo, w_a + 8u * (uint32_t)(cls * S2_WROW), L, len, A, B, ctr);
+                    double o = surface_eval(img_a + 8u * (uint32_t)(L - lo), w_a + 8u * (uint32_t)(cls * S2_WROW), len, A, k ? B : 0, ctr);
                     o = (SRC ? ssv[q] : 0.0) + o;
                     if ((dm >> (cls - 1)) & 1u) o = 0.0;
                     if (v < cp_surf) {
@@ -622,7 +638,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
 
 size_t slab2_lds_bytes(const MeshDev &mesh)
 {
-    return sizeof(double) * (size_t)(2 * S2_WSZ + 2 * S2_RED + S2_TAB + S2_MAXCELLS / 2 + 2 * (size_t)mesh.slab.lds_nodes);
+    return sizeof(double) * (size_t)(2 * S2_WSZ + 2 * S2_RED + S2_TAB + S2_MAXCELLS / 2 + S2_GUARD + 2 * (size_t)mesh.slab.lds_nodes);
 }
 
 }  // namespace
@@ -631,7 +647,7 @@ bool apply_slab2_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, co
 {
     // (flags bit 2, the restriction through the window, keeps k_apply_slab: its evaluation lists do not hold consecutive slots;
     //  bit 3, the driver integrals, has its own instantiations there)
-    if (!L.apply_slab2 || lv.dim != 3 || lv.ncls != 15 || !mesh.slab.head || mesh.slab.nslab < 2 || mesh.slab.nslab > S2_MAXSLAB ||
+    if (!L.apply_slab2 || lv.dim != 3 || lv.ncls != 15 || lv.m + 2 > S2_GUARD || !mesh.slab.head || mesh.slab.nslab < 2 || mesh.slab.nslab > S2_MAXSLAB ||
         mesh.slab.max_surf > s2_smax(L.slab2_loaders == 8 ? 8 : 4) * (S2_NT - 64 * (L.slab2_loaders == 8 ? 8 : 4)) || (a.flags & 8) || (((a.flags & 4) != 0) != (a.out_ld != 0)) ||
         a.xcoarse || a.rcoarse)      // (level transfers folded into an apply: the LDS-resident kernels of levels 5 and 6 only)
         return false;
