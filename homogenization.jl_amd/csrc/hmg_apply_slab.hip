@@ -28,7 +28,11 @@ namespace hmg {
 namespace {
 
 #ifdef HMG_PHASE_TIMING   // dev build: thread 0 (a loader) and thread 512 (an evaluator) add up their work and barrier-wait times
-#define S2_T0() long long _tl = wall_clock64(); double _ph[4] = {0, 0, 0, 0}; const long long _tstart = _tl
+#define S2_T0() long long _tl = wall_clock64(); double _ph[6] = {0, 0, 0, 0, 0, 0}; const long long _tstart = _tl; long long _tb = _tl; double _ws = 0, _ws2 = 0, _wn = 0, _wmx = 0
+// every wave: its time from a step barrier's exit to its arrival at the next one -- sum, sum of squares, count, maximum (tools/dev/slab2_wave_timing.py)
+#define S2_ARRIVE() do { const double _d = (double)(wall_clock64() - _tb); _ws += _d; _ws2 += _d * _d; _wn += 1.0; _wmx = _d > _wmx ? _d : _wmx; } while (0)
+#define S2_LEAVE() do { _tb = wall_clock64(); } while (0)
+#define S2_STORE_WAVE() do { if (a.blockpart && (threadIdx.x & 63) == 0) { double *_o = a.blockpart + 2 * (size_t)a.nwork + 20 * (size_t)gridDim.x + 64 * (size_t)blockIdx.x + 4 * (threadIdx.x >> 6); _o[0] = _ws; _o[1] = _ws2; _o[2] = _wn; _o[3] = _wmx; } } while (0)
 #define S2_PHASE(i)                          \
     do {                                     \
         const long long _n = wall_clock64(); \
@@ -42,25 +46,30 @@ namespace {
             _o[0] = (double)_tstart;                                                     \
             for (int _q = 0; _q < 4; ++_q) _o[1 + _q] = _ph[_q];                         \
             _o[5] = (double)wall_clock64();                                              \
+            _o[6] = _ph[4];                                                              \
+            _o[7] = _ph[5];                                                              \
         }                                                                                \
     } while (0)
-// shader-clock cycles of the pieces of one interior node evaluation (the first of every chunk), summed: decode, LDS batch, arithmetic + store
+// shader-clock cycles of the pieces of one interior node evaluation (every one of the first evaluator wave), summed: decode, LDS batch, arithmetic
 #define S2_CYC_DECL() double _cy[4] = {0, 0, 0, 0}; long long _c0 = 0, _c1 = 0, _c2 = 0
 #define S2_CYC(i) _c##i = (long long)__builtin_readcyclecounter()
-#define S2_CYC_ADD() do { long long _c3 = (long long)__builtin_readcyclecounter(); _cy[0] += (double)(_c1 - _c0); _cy[1] += (double)(_c2 - _c1); _cy[2] += (double)(_c3 - _c2); _cy[3] += 1.0; } while (0)
+#define S2_CYC_ADD(dep) do { asm volatile("" : "+v"(dep)); long long _c3 = (long long)__builtin_readcyclecounter(); _cy[0] += (double)(_c1 - _c0); _cy[1] += (double)(_c2 - _c1); _cy[2] += (double)(_c3 - _c2); _cy[3] += 1.0; } while (0)
 #define S2_CYC_STORE() do { if (a.blockpart && rt == 0) { double *_o = a.blockpart + 2 * (size_t)a.nwork + 16 * (size_t)gridDim.x + 4 * (size_t)blockIdx.x; for (int _q = 0; _q < 4; ++_q) _o[_q] = _cy[_q]; } } while (0)
 #else
 #define S2_T0()
+#define S2_ARRIVE()
+#define S2_LEAVE()
+#define S2_STORE_WAVE()
 #define S2_PHASE(i)
 #define S2_STORE(base)
 #define S2_CYC_DECL()
 #define S2_CYC(i)
-#define S2_CYC_ADD()
+#define S2_CYC_ADD(dep)
 #define S2_CYC_STORE()
 #endif
 
 constexpr int S2_NT = 1024;        // threads per workgroup
-// loader threads NL = 64 x NLW (the first NLW waves), evaluator threads NE = 1024 - NL: NLW = 4 or 8 (option slab2_loaders)
+// loader threads NL = 64 x NLW (the first NLW waves), evaluator threads NE = 1024 - NL: NLW = 4 (operator applies) or 8 (the restriction through the window: an eighth of the nodes is evaluated)
 constexpr int S2_WROW = 16;        // doubles per class row of the weight table in LDS (128-B rows)
 constexpr int S2_WSZ = 15 * S2_WROW;
 constexpr int S2_RED = 16;         // per cell parity: 12 evaluator waves' p.Ap, 4 loader waves' r.r
@@ -69,7 +78,7 @@ constexpr int S2_MAXSLAB = 16;
 constexpr int S2_GUARD = 72;       // doubles of zeros below window 0: what the in-plane taps of plane 0's first rows address (up to m + 2 entries below the cell)
 constexpr int S2_MAXCELLS = 1024;  // cells per workgroup whose ids are staged in LDS (more: the launch takes k_apply_slab)
 __host__ __device__ constexpr int s2_smax(int nlw) { return nlw == 4 ? 4 : 6; }   // rows (of NE) of surface entries per slab (more: k_apply_slab)
-constexpr int S2_U_MAX = 4;        // interior rows per evaluator chunk
+__host__ __device__ constexpr int s2_umax(int nlw) { return nlw == 4 ? 8 : 4; }   // rows (of NE) of interior entries per slab (more: k_apply_slab)
 // loader: a row is R x 256 slots -- the scalar bookkeeping of a row is paid once per R slots of a lane; D rows lie between the request
 // of a row's data and its use (its addressing words: twice that).  NS streams of 8 B per slot, 256 lanes: 48 / 64 / 72 KB in flight
 // per CU -- 25 / 49 / 49 KB, what 13 GB/s per CU (the share of 3.3 TB/s read) need at 2-4 us of loaded latency -- in 48-72 VGPRs of ring
@@ -111,46 +120,6 @@ __device__ __forceinline__ void read15(uint32_t ap, int len, int A, int B, doubl
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
                    "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14])
                  : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(pd), "v"(a6));
-}
-
-// The same reads WITHOUT the wait (form (ii) of the guide's asm rules): the values count as written for the compiler, so nothing may
-// touch them before wait15() has named them all -- the interior loop issues the reads of node q+1, then waits for node q's (LDS reads
-// return in order: at most 15 outstanding = the older 15 have landed) and runs node q's arithmetic while the LDS serves node q+1.
-__device__ __forceinline__ void issue15(uint32_t ap, int len, int A, int B, double (&v)[15])
-{
-    const uint32_t a0 = ap - 8u;
-    const uint32_t a1 = ap + 8u * (uint32_t)(len - 1);
-    const uint32_t a2 = ap - 8u * (uint32_t)(len + 1);
-    const uint32_t pu = ap + 8u * (uint32_t)A, pd = ap - 8u * (uint32_t)B;
-    const uint32_t a3 = pu - 8u * (uint32_t)len;
-    const uint32_t a4 = pu - 8u;
-    const uint32_t a6 = pd + 8u * (uint32_t)len;
-    asm volatile("ds_read_b64 %0, %15 offset:8\n\t"
-                 "ds_read_b64 %1, %15 offset:16\n\t"
-                 "ds_read_b64 %2, %15\n\t"
-                 "ds_read_b64 %3, %16\n\t"
-                 "ds_read_b64 %4, %17 offset:8\n\t"
-                 "ds_read_b64 %5, %16 offset:8\n\t"
-                 "ds_read_b64 %6, %17\n\t"
-                 "ds_read_b64 %7, %18\n\t"
-                 "ds_read_b64 %8, %21 offset:8\n\t"
-                 "ds_read_b64 %9, %19\n\t"
-                 "ds_read_b64 %10, %20 offset:8\n\t"
-                 "ds_read_b64 %11, %19 offset:8\n\t"
-                 "ds_read_b64 %12, %20\n\t"
-                 "ds_read_b64 %13, %18 offset:8\n\t"
-                 "ds_read_b64 %14, %21"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
-                   "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14])
-                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(pd), "v"(a6));
-}
-template <int N>   // wait until at most N LDS operations are outstanding; the values named become readable
-__device__ __forceinline__ void wait15(double (&v)[15])
-{
-    asm volatile("s_waitcnt lgkmcnt(%15)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
-                   "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14])
-                 : "i"(N));
 }
 
 // Surface node: the interior node's addressing (seven address registers, read15's tap order) and, per statement, eight / seven
@@ -229,9 +198,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
 {
     constexpr int NDIR = 15, NTERM = 7;
     constexpr int NL = 64 * NLW, NE = S2_NT - NL, S2_SMAX = s2_smax(NLW);
-    constexpr int S2_U = S2_U_MAX;
-    constexpr bool PIPE = false;     // interior: node q + 1's LDS reads in flight during node q's arithmetic (issue15 / wait15).  Measured round 5:
-                                     // no gain (27.2 vs 28.0 us per cell) and WRONG results -- the compiler moved the unwaited values; kept for the record
+    constexpr int S2_U = s2_umax(NLW);
     extern __shared__ double smem[];
     double *Wt = smem;                              // [2][S2_WSZ]  class weight tables of the cell being evaluated / being loaded
     double *red = smem + 2 * S2_WSZ;                // [2][S2_RED]
@@ -434,7 +401,9 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                             rr = 0.0;
                         }
                         S2_PHASE(0);                                            // (0: filling a window)
+                        S2_ARRIVE();
                         __syncthreads();
+                        S2_LEAVE();
                         S2_PHASE(1);                                            // (1: waiting for the evaluators)
                     }
                     advance(cp);
@@ -448,6 +417,7 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
         }
         __syncthreads();                            // (the evaluators' last step)
         S2_STORE(0);
+        S2_STORE_WAVE();
     } else {
         // ------------------------------------------------------------------------------------------------------------------
         // EVALUATORS: at iteration g they evaluate step g from window g & 1
@@ -461,8 +431,8 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
         uint32_t dm = 0, mq[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
         double w0[NDIR];
         // requested one step ahead, in front of the barrier (nothing of it depends on the windows): addressing words, slots and source
-        // values of this thread's surface entries, words and source values of its first interior chunk.  Rows are completed with
-        // copies of their last entry.
+        // values of this thread's surface entries and of its interior entries (all S2_U rows of them: the host sends slabs with
+        // more to k_apply_slab).  Rows are completed with copies of their last entry.
         uint32_t sw[S2_SMAX], iw[S2_U];
         int ss[S2_SMAX], is[S2_U];
         double ssv[S2_SMAX], isv[S2_U];
@@ -496,10 +466,57 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                 for (int q = 0; q < S2_SMAX; ++q) ssv[q] = sc[ss[q]];
             }
         };
+        // The results of step g are STORED AT THE START OF STEP g + 1, behind the wait for that step's requested values.  The memory
+        // counter of a wave counts loads and stores alike and in order: a wait for requested values is also a wait for every store
+        // issued before it, and a store is slow to issue and to be acknowledged while the loaders keep the CU's memory pipeline full
+        // (per-wave step times, round 5: 5.2 us per step with the evaluators' stores, 3.9 us with none).  Stored one step late, the
+        // youngest store a wait meets is a whole step old, and the step's evaluation holds no memory instruction at all.
+        // (Same-box A/B on config 5's share: 6.60-6.62 -> 6.33-6.37 ms per apply on one box, within the noise on two others.)
+        double od[S2_U], sd[S2_SMAX];               // results of the previous step: interior rows, surface rows
+        int dis[S2_U], dss[S2_SMAX];                // their output slots (interior: SLOT launches only)
+        double *d_oc = nullptr;
+        int d_nint = 0, d_tfirst = 0, d_surf = 0;
+        auto flush = [&]() {
+            if (!OUT) return;
+            if constexpr (SLOT) {
+#pragma unroll
+                for (int q = 0; q < S2_U; ++q) {
+                    const int v = q * NE + rt;
+                    if (q * NE + wbase < d_nint) {
+                        if (v < d_nint) st_global(d_oc + dis[q], od[q]);
+                    }
+                }
+            } else {
+                // interior rows in pairs, 16 bytes per lane: the even lane of a lane pair stores row q's two results (its own and
+                // its neighbour's), the odd lane row q + 1's -- half the store instructions (their issue is what an evaluator waits for)
+                const int odd = rt & 1;
+#pragma unroll
+                for (int q = 0; q < S2_U; q += 2) {
+                    if (q * NE + wbase < d_nint) {
+                        const double other = pair_swap_f64(odd ? od[q] : od[q + 1]);
+                        const double lo = odd ? other : od[q], hi = odd ? od[q + 1] : other;
+                        const int v0 = (q + odd) * NE + (rt & ~1);              // the pair's first entry
+                        double *dst = d_oc + (d_tfirst + v0);
+                        if (v0 + 1 < d_nint)
+                            st_global2(dst, lo, hi);
+                        else if (v0 < d_nint)
+                            st_global(dst, lo);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < S2_SMAX; ++q) {
+                const int v = q * NE + rt;
+                if (q * NE + wbase < d_surf) {
+                    if (v < d_surf) st_global(d_oc + dss[q], sd[q]);
+                }
+            }
+        };
         request(0, cell);
         S2_CYC_DECL();
         S2_T0();
         __syncthreads();                                            // (the loaders fill window 0)
+        S2_LEAVE();
         S2_PHASE(3);
         for (int64_t g = 0; g < T; ++g) {
             const int b = (int)(g & 1);
@@ -509,75 +526,58 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
 #pragma unroll
                 for (int q = 0; q < 4; ++q) mq[q] = has_mult ? (uint32_t)sgpr((int)mq_n[q]) : 0x01010101u;
             }
+            // (the requested values have arrived: everything below this statement -- the stores of the previous step's results first --
+            //  is issued behind the wait for them)
+#pragma unroll
+            for (int q = 0; q < S2_U; ++q) {
+                asm volatile("" : "+v"(iw[q]));
+                if (SLOT) asm volatile("" : "+v"(is[q]));
+                if (SRC) asm volatile("" : "+v"(isv[q]));
+            }
+#pragma unroll
+            for (int q = 0; q < S2_SMAX; ++q) {
+                asm volatile("" : "+v"(sw[q]), "+v"(ss[q]));
+                if (SRC) asm volatile("" : "+v"(ssv[q]));
+            }
+            S2_PHASE(4);                                            // (4: waiting for the requested values)
+            flush();
+            S2_PHASE(5);                                            // (5: issuing the previous step's stores)
             if (sl == 0) {
                 const double *W = Wt + (size_t)(ci & 1) * S2_WSZ;
 #pragma unroll
                 for (int d = 0; d < NDIR; ++d) w0[d] = to_sgpr(lds_ld(W + d));   // interior weight row (class 0), SGPR-resident
             }
-            const double *sc = SRC ? a.src + cell * lv.ld : nullptr;
-            double *oc = OUT ? a.out + cell * (a.out_ld ? a.out_ld : (int64_t)lv.ld) : nullptr;
             const int *t = tab + 16 * sl;
-            const int cp_off = sgpr(t[8]), cp_surf = sgpr(t[9]), n_int = sgpr(t[10]), t_first = sgpr(t[11]), nrow_i = sgpr(t[12]),
-                      lo = sgpr(t[3]);
+            const int cp_surf = sgpr(t[9]), n_int = sgpr(t[10]), t_first = sgpr(t[11]), lo = sgpr(t[3]);
             const uint32_t img_a = img_a0 + (uint32_t)b * 8u * (uint32_t)win;     // LDS byte address of lattice position lo
             const uint32_t w_a = lds_addr(Wt + (size_t)(ci & 1) * S2_WSZ);
-            const int ib = cp_off + cp_surf;
+            d_oc = OUT ? a.out + cell * (a.out_ld ? a.out_ld : (int64_t)lv.ld) : nullptr;
+            d_nint = n_int;
+            d_tfirst = t_first;
+            d_surf = cp_surf;
 
-            // cell interior: one weight row for all nodes; chunks of S2_U rows, the next chunk's words and source values requested
-            // in front of this chunk's evaluation
-            for (int r0 = 0; r0 < nrow_i; r0 += S2_U) {
-                uint32_t nw[S2_U];
-                int ns[S2_U];
-                double nsv[S2_U];
+            // cell interior: one weight row for all nodes
 #pragma unroll
-                for (int q = 0; q < S2_U; ++q) {
-                    const int v = min((r0 + S2_U + q) * NE + rt, n_int - 1);
-                    nw[q] = st.cp_word[ib + v];
-                    if (SLOT) ns[q] = (int)st.cp_slot[ib + v];
-                    if (SRC) nsv[q] = sc[t_first + v];
-                }
-                // node q's arithmetic runs while the LDS serves node q + 1 (issue15 / wait15)
-                double xa[15], xb[15];
-                if (PIPE) {
+            for (int q = 0; q < S2_U; ++q) {
+                const int v = q * NE + rt;
+                if (q * NE + wbase < n_int) {                                   // (this wave's 64 entries of the row: none beyond the list)
+                    double x[15];
                     int L, len, A, B;
-                    decode_lattice(iw[0], m, L, len, A, B);
-                    issue15(img_a + 8u * (uint32_t)(L - lo), len, A, B, xa);
-                }
+                    S2_CYC(0);
+                    decode_lattice(iw[q], m, L, len, A, B);
+                    const uint32_t ap = img_a + 8u * (uint32_t)(L - lo);
+                    S2_CYC(1);
+                    read15(ap, len, A, B, x);
+                    S2_CYC(2);
+                    double acc = w0[1] * x[1];                                  // (the order hipcc contracts stencil_eval_v to)
+                    acc = __builtin_fma(w0[0], x[0], acc);
 #pragma unroll
-                for (int q = 0; q < S2_U; ++q) {
-                    const int v = (r0 + q) * NE + rt;
-                    double (&x)[15] = (q & 1) ? xb : xa;
-                    double (&xn)[15] = (q & 1) ? xa : xb;
-                    const bool more = q + 1 < S2_U && r0 + q + 1 < nrow_i;      // (uniform)
-                    if ((r0 + q) * NE + wbase < n_int) {                          // (this wave's 64 entries of the row: none beyond the list)
-                        if (!PIPE) {
-                            int L, len, A, B;
-                            decode_lattice(iw[q], m, L, len, A, B);
-                            read15(img_a + 8u * (uint32_t)(L - lo), len, A, B, x);
-                        } else if (more) {
-                            int L, len, A, B;
-                            decode_lattice(iw[q + 1 < S2_U ? q + 1 : q], m, L, len, A, B);
-                            issue15(img_a + 8u * (uint32_t)(L - lo), len, A, B, xn);
-                            wait15<15>(x);
-                        } else {
-                            wait15<0>(x);
-                        }
-                        double acc = w0[1] * x[1];                              // (the order hipcc contracts stencil_eval_v to)
-                        acc = __builtin_fma(w0[0], x[0], acc);
-#pragma unroll
-                        for (int d = 2; d < NDIR; ++d) acc = __builtin_fma(w0[d], x[d], acc);
-                        const double o = (SRC ? isv[q] : 0.0) + acc;
-                        if (v < n_int) {
-                            if (OUT) st_global(oc + (SLOT ? is[q] : t_first + v), o);
-                            if (FUSED) pap = __builtin_fma(x[0], o, pap);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < S2_U; ++q) {
-                    iw[q] = nw[q];
-                    if (SLOT) is[q] = ns[q];
-                    if (SRC) isv[q] = nsv[q];
+                    for (int d = 2; d < NDIR; ++d) acc = __builtin_fma(w0[d], x[d], acc);
+                    double o = (SRC ? isv[q] : 0.0) + acc;
+                    S2_CYC_ADD(o);
+                    od[q] = o;
+                    if (SLOT) dis[q] = is[q];
+                    if (FUSED && v < n_int) pap = __builtin_fma(x[0], o, pap);
                 }
             }
             S2_PHASE(0);                                            // (0: cell interior)
@@ -592,14 +592,13 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                     double o = surface_eval(img_a + 8u * (uint32_t)(L - lo), w_a + 8u * (uint32_t)(cls * S2_WROW), len, A, k ? B : 0, ctr);
                     o = (SRC ? ssv[q] : 0.0) + o;
                     if ((dm >> (cls - 1)) & 1u) o = 0.0;
-                    if (v < cp_surf) {
-                        if (OUT) st_global(oc + ss[q], o);
-                        if (FUSED) {
-                            const int en = cls - 1;
-                            const uint32_t word = en < 4 ? mq[0] : en < 8 ? mq[1] : en < 12 ? mq[2] : mq[3];
-                            const uint32_t mu = (word >> (8 * (en & 3))) & 0xffu;
-                            pap += (double)mu * (ctr * o);
-                        }
+                    sd[q] = o;
+                    dss[q] = ss[q];
+                    if (FUSED && v < cp_surf) {
+                        const int en = cls - 1;
+                        const uint32_t word = en < 4 ? mq[0] : en < 8 ? mq[1] : en < 12 ? mq[2] : mq[3];
+                        const uint32_t mu = (word >> (8 * (en & 3))) & 0xffu;
+                        pap += (double)mu * (ctr * o);
                     }
                 }
             }
@@ -619,7 +618,9 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
             }
             if (g + 1 < T) request(sl, cell);
             S2_PHASE(1);                                            // (1: surface entities)
+            S2_ARRIVE();
             __syncthreads();
+            S2_LEAVE();
             S2_PHASE(2);                                            // (2: waiting for the loaders)
             if (FUSED && cell_done && rt == 0) {                    // (partials of this parity are written again two cells on)
                 double s_pap = 0.0, s_rr = 0.0;
@@ -631,7 +632,9 @@ k_apply_slab2(LevelDev lv, const double *__restrict__ coef, const uint16_t *__re
                 a.blockpart[2 * cell_was + 1] = s_rr;
             }
         }
+        flush();                                                    // (the last step's results)
         S2_STORE(8);
+        S2_STORE_WAVE();
         S2_CYC_STORE();
     }
 }
@@ -647,8 +650,9 @@ bool apply_slab2_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, co
 {
     // (flags bit 2, the restriction through the window, keeps k_apply_slab: its evaluation lists do not hold consecutive slots;
     //  bit 3, the driver integrals, has its own instantiations there)
+    const int nlw = (a.flags & 4) ? 8 : 4;      // loader waves (launch_slab2)
     if (!L.apply_slab2 || lv.dim != 3 || lv.ncls != 15 || lv.m + 2 > S2_GUARD || !mesh.slab.head || mesh.slab.nslab < 2 || mesh.slab.nslab > S2_MAXSLAB ||
-        mesh.slab.max_surf > s2_smax(L.slab2_loaders == 8 ? 8 : 4) * (S2_NT - 64 * (L.slab2_loaders == 8 ? 8 : 4)) || (a.flags & 8) || (((a.flags & 4) != 0) != (a.out_ld != 0)) ||
+        mesh.slab.max_surf > s2_smax(nlw) * (S2_NT - 64 * nlw) || mesh.slab.max_int > s2_umax(nlw) * (S2_NT - 64 * nlw) || (a.flags & 8) || (((a.flags & 4) != 0) != (a.out_ld != 0)) ||
         a.xcoarse || a.rcoarse)      // (level transfers folded into an apply: the LDS-resident kernels of levels 5 and 6 only)
         return false;
     return slab2_lds_bytes(mesh) <= 160 * 1024;
@@ -657,7 +661,7 @@ bool apply_slab2_ok(const Launch &L, const LevelDev &lv, const MeshDev &mesh, co
 template <bool FUSED, int NS, bool SRC, bool OUT, bool SLOT = false>
 static void launch_slab2(const Launch &L, const LevelDev &lv, const MeshDev &mesh, const ApplyArgs &a)
 {
-    auto kern = L.slab2_loaders == 8 ? k_apply_slab2<FUSED, NS, SRC, OUT, 8, SLOT> : k_apply_slab2<FUSED, NS, SRC, OUT, 4, SLOT>;
+    auto kern = k_apply_slab2<FUSED, NS, SRC, OUT, SLOT ? 8 : 4, SLOT>;
     const size_t bytes = slab2_lds_bytes(mesh);
     HMG_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     const int64_t nblocks = a.cell_list ? a.ncell_list : a.ncells_prefix ? a.ncells_prefix : mesh.ncells;

@@ -126,7 +126,7 @@ struct LevelBufs {
     DevBuf<uint32_t> slab_ld_word, slab_cp_word, slab_rs_word;
     DevBuf<uint16_t> slab_cp_slot, slab_rs_slot;
     DevBuf<double> rtab;   // restriction weights in class-table layout (slab levels)
-    int nslab = 0, slab_lds_nodes = 0, slab_max_surf = 0, slab_rs_max_surf = 0;
+    int nslab = 0, slab_lds_nodes = 0, slab_max_surf = 0, slab_rs_max_surf = 0, slab_max_int = 0, slab_rs_max_int = 0;
     DevBuf<uint32_t> pos32, pos32w, sweep32, par32, blk_word;
     DevBuf<uint64_t> par64;
     DevBuf<uint16_t> clpos;
@@ -759,6 +759,7 @@ static void upload_levels(hmg_grid *g)
                     for (int q = b0 + 1; q < e0; ++q)
                         if (cps[(size_t)q] != cps[(size_t)q - 1] + 1) throw std::runtime_error("apply slabs: interior slots of a slab are not consecutive");
                     B.slab_max_surf = std::max(B.slab_max_surf, head[sl * 8 + 5]);
+                    B.slab_max_int = std::max(B.slab_max_int, head[sl * 8 + 4] - head[sl * 8 + 5]);
                 }
                 ldw.resize(ldw.size() + TABLE_PAD, 0u);
                 cpw.resize(cpw.size() + TABLE_PAD, 0u);
@@ -799,6 +800,7 @@ static void upload_levels(hmg_grid *g)
                         }
                         rhead[sl * 8 + 4] = (int)rsw.size() - rhead[sl * 8 + 3];
                         B.slab_rs_max_surf = std::max(B.slab_rs_max_surf, rhead[sl * 8 + 5]);
+                        B.slab_rs_max_int = std::max(B.slab_rs_max_int, rhead[sl * 8 + 4] - rhead[sl * 8 + 5]);
                     }
                     if ((int)rsw.size() != C.nf) throw std::runtime_error("slab restriction: lists do not cover the coarse cell");
                     rsw.resize(rsw.size() + TABLE_PAD, 0u);
@@ -1129,6 +1131,7 @@ void set_slab(hmg_grid *g, const LevelDev &lv)
     g->md.slab.nslab = B.nslab;
     g->md.slab.lds_nodes = B.slab_lds_nodes;
     g->md.slab.max_surf = B.slab_max_surf;
+    g->md.slab.max_int = B.slab_max_int;
 }
 
 // every operator apply goes through here: optional HIP-event bracketing for bench.py's roofline
@@ -1176,6 +1179,7 @@ void restrict_level(hmg_grid *g, int level_fine, const double *rf, double *bc)
         st.nslab = B.nslab;
         st.lds_nodes = B.slab_lds_nodes;
         st.max_surf = B.slab_rs_max_surf;
+        st.max_int = B.slab_rs_max_int;
         launch_restrict_slab(g->ctx->L, fr, g->md, st, coarse.ld, rf, bc);
         return;
     }
@@ -2397,7 +2401,6 @@ static int ctx_create(int device, void *stream, bool use_given, hmg_ctx **out)
     c->L.slab2_grid = 0;
     c->L.slab2_force = 0;
     c->L.restrict_slab2 = 1;
-    c->L.slab2_loaders = 4;   // (same-box A/B at config 5: 117.7 ms old kernel, 117.2-119.0 with 8 loader waves, 113.1-113.6 with 4)
     c->L.apply_pack = 1;    // level 2: four cells per wave
     c->L.apply_small = 1;   // levels 2-4: pipelined one-wave kernel (hmg_apply_small.hip)
     c->L.n_small_launches = &c->small_launches;
@@ -2469,8 +2472,6 @@ int hmg_ctx_set_option(hmg_ctx *ctx, const char *name, int64_t value)
         ctx->L.weight_cache = value != 0;
     else if (n == "apply_slab2")           // 1 = default; 0: cells larger than the LDS keep k_apply_slab (A/B knob)
         ctx->L.apply_slab2 = value != 0;
-    else if (n == "slab2_loaders")         // loader waves of its 16: 4 (default) or 8
-        ctx->L.slab2_loaders = value == 8 ? 8 : 4;
     else if (n == "restrict_slab2")        // 1 = default; 0: the stand-alone restriction keeps k_apply_slab (A/B knob)
         ctx->L.restrict_slab2 = value != 0;
     else if (n == "slab2_force")           // experiment: level 6 through the window kernel (needs HMG_SLAB_LDS_KB <= 30 at grid creation)

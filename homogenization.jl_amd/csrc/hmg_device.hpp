@@ -69,6 +69,7 @@ struct SlabTables {
     const uint16_t *cp_slot;     // evaluated slots: storage slot                                  (+ TABLE_PAD)
     int nslab, lds_nodes;
     int max_surf;                // most surface entries (cp_surf) of any slab
+    int max_int;                 // most interior entries (cp_cnt - cp_surf) of any slab
 };
 
 struct MeshDev {
@@ -173,7 +174,6 @@ struct Launch {
     int64_t slab2_grid;   // its grid (0: one workgroup per CU)
     int restrict_slab2;   // 1 (default): the stand-alone restriction of levels with slab tables goes through it too (eight loader waves)
     int slab2_force;      // 1 (experiment): every 3D level with slab tables of two slabs or more takes it (level 6 with HMG_SLAB_LDS_KB <= 30)
-    int slab2_loaders;    // its loader waves: 4 (default) or 8 of the workgroup's 16
     int64_t persistent_waves;   // grid of the one-wave apply instantiations (default 32 per CU: what is resident at once); they
                           // loop over the cells.  Larger than the number of cells = one workgroup per cell
 };

@@ -1590,10 +1590,8 @@ void launch_restrict_slab(const Launch &L, const LevelDev &fine_rtab, const Mesh
         // the loaders set the pace (option restrict_slab2 = 0: k_apply_slab as in rounds 1-4; the coarse vector is the same to the last bit)
         MeshDev m2 = mesh;
         m2.slab = st;
-        Launch L2 = L;
-        L2.slab2_loaders = 8;
-        if (L.restrict_slab2 && apply_slab2_ok(L2, fine_rtab, m2, a)) {
-            launch_apply_slab2(L2, fine_rtab, m2, a, false);
+        if (L.restrict_slab2 && apply_slab2_ok(L, fine_rtab, m2, a)) {
+            launch_apply_slab2(L, fine_rtab, m2, a, false);
             return;
         }
     }

@@ -43,6 +43,25 @@ __device__ __forceinline__ void st_global(double *p, double v)
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v));
 }
 
+// two consecutive doubles in one store instruction (8-byte aligned address).  A store-heavy tail is bound by the number of store
+// INSTRUCTIONS a CU can issue, not by their bytes (MI355X_MICROARCH.md, "store-ISSUE-bound"): 16 bytes per lane halve it.
+typedef double hmg_f64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_global2(double *p, double lo, double hi)
+{
+    hmg_f64x2 v;
+    v.x = lo;
+    v.y = hi;
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v));
+}
+
+// the value of the other lane of this lane's pair (lanes 2 i and 2 i + 1)
+__device__ __forceinline__ double pair_swap_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);   // quad_perm [1, 0, 3, 2]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------

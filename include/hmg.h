@@ -89,8 +89,7 @@ int hmg_ctx_release_memory(hmg_ctx *ctx);
  * from the class-weight cache; levels 2-4 by the pipelined one-wave kernel, level 2 four cells to a wave, hmg_apply_small.hip),
  * "apply_slab2" (1 = default: cells larger than the LDS -- 3D level 7 -- are applied by ONE persistent 1024-thread workgroup per CU
  * whose waves have roles, hmg_apply_slab.hip: loader waves stream the next k-plane window from HBM while evaluator waves work on the
- * current one; 0 = the rolling-window kernel of rounds 1-4, same arithmetic per node; "slab2_loaders": its loader waves, 4 = default
- * or 8; "slab2_grid": its workgroups, 0 = one per CU; "restrict_slab2": 1 = default, the stand-alone restriction of such a level goes
+ * current one; 0 = the rolling-window kernel of rounds 1-4, same arithmetic per node; "slab2_grid": its workgroups, 0 = one per CU; "restrict_slab2": 1 = default, the stand-alone restriction of such a level goes
  * through it too; "slab2_force": experiment, level 6 through it -- needs HMG_SLAB_LDS_KB <= 30 when the grid is created),
  * "time_apply"; "coarse_rtol" and "coarse_poly_ratio" (20: the interval [lmax / ratio, lmax]) via hmg_ctx_set_option_f64.  Environment: HMG_SLAB_LDS_KB (LDS window of the slab
  * kernel for cells larger than the LDS, default 70). */

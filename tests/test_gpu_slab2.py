@@ -26,17 +26,15 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(scope="module", params=[(3, 0, 8), (3, 7, 8), (3, 16, 4), (2, 0, 4), (1, 0, 8)],
-                ids=["162cells", "162cells-7wgs", "162cells-16wgs-4loaders", "48cells-4loaders", "6cells"])
+@pytest.fixture(scope="module", params=[(3, 0), (3, 7), (3, 16), (2, 0), (1, 0)],
+                ids=["162cells", "162cells-7wgs", "162cells-16wgs", "48cells", "6cells"])
 def case(request, ctx):
-    n, grid, loaders = request.param
+    n, grid = request.param
     base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, n, L, seed=3, values=(1.0, 100.0), lam=0.7)
     ctx.set_option("slab2_grid", grid)
-    ctx.set_option("slab2_loaders", loaders)
     g.ncubes = n
     yield ctx, g, op
     ctx.set_option("slab2_grid", 0)
-    ctx.set_option("slab2_loaders", 8)
     g.close()
 
 

@@ -135,8 +135,8 @@ def test_slab2_kernel_fits_one_workgroup_per_cu_without_scratch(tmp_path):
     for m in re.finditer(r"Function Name: _ZN3hmg\w*?13k_apply_slab2I(\w+?)EEvNS_8LevelDev.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)",
                          out.stderr, re.S):
         found[m.group(1)] = (int(m.group(2)), int(m.group(3)))
-    # <FUSED, NS, SRC, OUT> x loader waves {4, 8}: 14 combinations each, + the restriction form (SLOT)
-    assert len(found) >= 30, sorted(found)
+    # <FUSED, NS, SRC, OUT> with 4 loader waves: 14 combinations, + the restriction form (8 loader waves, SLOT)
+    assert len(found) == 15, sorted(found)
     for name, (vgprs, scratch) in found.items():
         assert vgprs <= 128 and scratch == 0, (name, vgprs, scratch)
     text = open(src).read()

@@ -53,14 +53,15 @@ if g.nf(L) > 20000 and ctx.counter("slab2_launches") > 0:
           f"{(max(ld[:, 5].max(), ev[:, 5].max()) - min(ld[:, 0].min(), ev[:, 0].min())) * tick / 1e6:.3f} ms; workgroup lifetime mean {life.mean():.1f} us")
     for name, col, arr in (("loaders: filling windows", 1, ld), ("loaders: waiting at the step barrier", 2, ld),
                            ("evaluators: cell interior", 1, ev), ("evaluators: surface entities", 2, ev),
-                           ("evaluators: waiting at the step barrier", 3, ev), ("evaluators: first window", 4, ev)):
+                           ("evaluators: waiting at the step barrier", 3, ev), ("evaluators: first window", 4, ev),
+                           ("evaluators: waiting for the requested words / values", 6, ev), ("evaluators: issuing the previous step's stores", 7, ev)):
         d = arr[:, col] * tick / 1e3
         print(f"  {name:44s} mean {d.mean():9.1f} us  ({100 * d.mean() / life.mean():4.1f} %)   per cell {d.mean() / (g.ncells() / nwg):7.2f} us")
     cy = raw[2 * g.ncells() + 16 * nwg: 2 * g.ncells() + 20 * nwg].reshape(nwg, 4)
     n = cy[:, 3].sum()
     if n > 0:
-        print(f"  one interior node evaluation (first of a chunk, wave 8), shader cycles: decode + addresses {cy[:, 0].sum() / n:6.0f}   "
-              f"15 LDS reads + wait {cy[:, 1].sum() / n:6.0f}   17 FP64 ops + store {cy[:, 2].sum() / n:6.0f}   ({n:.0f} samples)")
+        print(f"  one interior node evaluation (first evaluator wave, all its nodes), shader cycles: decode + addresses {cy[:, 0].sum() / n:6.0f}   "
+              f"15 LDS reads + wait {cy[:, 1].sum() / n:6.0f}   17 FP64 ops {cy[:, 2].sum() / n:6.0f}   ({n:.0f} samples)")
     sys.exit(0)
 if g.nf(L) > 20000:
     # k_apply_slab (cells larger than the LDS): thread 0's time per phase summed over the cell's slabs, barrier waits included
