@@ -140,3 +140,43 @@ def test_restriction_through_the_window_is_bit_identical(case):
     assert np.abs(out[1]).max() > 0
     np.testing.assert_array_equal(out[0], out[1])
     xf.close()
+
+
+def test_level6_cells_through_the_window_kernel(monkeypatch):
+    """Another geometry for the same kernel: level-6 cells (m = 32, 6 545 nodes) cut into slabs by a 28 KB window (HMG_SLAB_LDS_KB,
+    read when the grid is created) and sent through k_apply_slab2 by option slab2_force -- other row counts per slab, other parities
+    of the interior run (the paired 16-byte stores), more steps per cell -- against the LDS-resident kernels of level 6, whose
+    register-blocked walk adds the same taps in another order (1e-12), and against itself (bit-reproducible)."""
+    monkeypatch.setenv("HMG_SLAB_LDS_KB", "28")
+    c = hmg.Context(0)
+    L6 = 6
+    try:
+        base, cond, g, A = driver.checkerboard_problem(c, hmg.Tet64, 2, L6, seed=4, values=(1.0, 9.0), lam=0.3)
+        x = hmg.DeviceMatrix(g, L6).rand(11)
+        b = hmg.DeviceMatrix(g, L6).rand(12)
+
+        def run():
+            r = hmg.DeviceMatrix(g, L6)
+            hmg.apply_ex(-1.0, g, x, b, r, constrain=True)
+            st = hmg.LevelState(g, L6)
+            st.x.rand(5); st.b.rand(6)
+            hmg.broadcast_interfaces(st.x, g, L6)
+            hmg.apply_constraint(st.x, L6, g)
+            hmg.smoothing_steps(3, g, A, st, L6)
+            res = [v.to_host() for v in (r, st.x, st.r, st.p)]
+            r.close(); st.close()
+            return res
+        out = []
+        for force in (1, 1, 0):
+            c.set_option("slab2_force", force)
+            n0 = c.counter("slab2_launches")
+            out.append(run())
+            assert (c.counter("slab2_launches") > n0) == bool(force)
+        for a, a2, o in zip(*out):
+            assert np.isfinite(a).all() and np.abs(o).max() > 0
+            np.testing.assert_array_equal(a, a2)
+            assert np.abs(a - o).max() <= 1e-12 * np.abs(o).max()
+        x.close(); b.close(); g.close()
+    finally:
+        c.set_option("slab2_force", 0)
+        c.close()
