@@ -21,6 +21,8 @@ a = ap.parse_args()
 _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libhmg_hip_phase_timing.so")
 ctx = hmg.Context(0)
 ctx.set_option("apply_wg512", a.wg512)
+if a.levels < 7:
+    ctx.set_option("cell_order", 0)     # (the stamps of k_apply are indexed by cell and written by full-grid launches without a cell list)
 L = a.levels
 base, cond, g, op = driver.checkerboard_problem(ctx, hmg.Tet64, a.width, L, seed=0)
 x = hmg.DeviceMatrix(g, L).rand(1)
